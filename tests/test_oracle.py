@@ -1,0 +1,102 @@
+"""CPU tests that pin the oracle (oracle/paint_oracle.c): against the golden
+vectors produced by the compiled reference, against the reference's own
+known-answer tests, and live against oracle/_ref where that library exists."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth_np as sy
+from conftest import load_golden
+
+
+def test_oracle_matches_golden_stones_bytewise(golden):
+    g = golden
+    out = ol.oracle().paint_stones(g["seq"], g["r"], g["theta_painter"], g["theta_data"], g["wb"])
+    assert out.shape == g["stones"].shape
+    assert np.array_equal(out, g["stones"])
+
+
+def test_oracle_matches_golden_repaint(golden):
+    g = golden
+    if "rp0_wk" not in g:
+        pytest.skip("mixed-theta case has no RePaintSection fixture")
+    st = ol.decode_records(g["stones"])
+    for i in range(4):
+        w, k = (int(v) for v in g[f"rp{i}_wk"])
+        top, ls = ol.oracle().repaint_section(g["seq"], g["r"], g["theta_data"], int(st["a_snp"][w, k]),
+                                              int(st["b_snp"][w, k]), st["alpha"][w, k], st["beta"][w, k],
+                                              float(st["a_ls"][w, k]), float(st["b_ls"][w, k]), k)
+        assert np.array_equal(top.view(np.uint32), g[f"rp{i}_top"].view(np.uint32))
+        assert np.array_equal(ls.view(np.uint32), g[f"rp{i}_ls"].view(np.uint32))
+
+
+def test_record_layout_discrete_fields(golden):
+    """Record = i32 start, i32 end, {u64 1, u64 N, i32 snp, f32 ls, f32[N]} x 2
+    (src/fast_painting.cpp:603-615, src/collapsed_matrix.hpp:240-252)."""
+    g = golden
+    d = ol.decode_records(g["stones"])
+    W = len(g["wb"]) - 1
+    N = g["N"]
+    assert g["stones"].shape == (W, N, 56 + 8 * N)
+    for w in range(W):
+        assert (d["start"][w] == g["wb"][w]).all() and (d["end"][w] == g["wb"][w + 1] - 1).all()
+    assert (d["a_rows"] == 1).all() and (d["b_rows"] == 1).all()
+    assert (d["a_cols"] == N).all() and (d["b_cols"] == N).all()
+    assert (d["a_snp"][0] == 0).all() and (d["b_snp"][W - 1] == g["L"] - 1).all()
+    assert (d["a_snp"] < d["b_snp"]).all()
+    # alpha[k] is 0 in every stone; beta[k] is 0 except in stones taken at the last SNP, where it is 1
+    for k in range(N):
+        assert (d["alpha"][:, k, k] == 0).all()
+        at_end = d["b_snp"][:, k] == g["L"] - 1
+        assert (d["beta"][at_end, k, k] == 1).all() and (d["beta"][~at_end, k, k] == 0).all()
+
+
+def test_fast_log_error_bound():
+    """test/test_log.cpp:6-15: |fast_log(x) - log(x)| < 0.007 over decades 1e-4..1e4."""
+    fl = ol.oracle().fast_log
+    for e in range(-4, 5):
+        x = 10.0 ** e
+        assert abs(fl(x) - math.log(x)) < 0.007
+    xs = np.exp(np.random.default_rng(1).uniform(math.log(1e-30), math.log(1e30), 2000))
+    assert max(abs(fl(float(np.float32(x))) - math.log(float(np.float32(x)))) for x in xs) < 0.007
+
+
+@pytest.mark.parametrize("name", ["toy_r0"])
+def test_known_answer_mismatch_counts(name):
+    """Restates test/test_painting.cpp:98-133 on the oracle: with r = 0 the
+    posterior is constant along the sequence and its log, in units of
+    fast_log(theta/(1-theta)), is the asymmetric mismatch count d[k][n]."""
+    g = load_golden(name)
+    o = ol.oracle()
+    seq, d = sy.toy_test_painting()
+    assert np.array_equal(seq, g["seq"]) and np.array_equal(d, g["expected_d"])
+    N, L, theta = 5, 10, 0.025
+    r = np.zeros(L)
+    pt = np.float32(theta / (N - 1.0) - (1 - theta) / (N - 1.0))
+    pn = np.float32((1 - theta) / (N - 1.0))
+    rescale = o.fast_log(theta / (1.0 - theta))
+    for k in range(N):
+        ab = np.array([np.float32(float(seq[0, k] > seq[0, n])) * pt + pn for n in range(N)], dtype=np.float32)
+        top, ls = o.repaint_section(seq, r, theta, 0, L - 1, ab, np.ones(N, np.float32), 0.0, 0.0, k)
+        assert np.array_equal(top.view(np.uint32), g[f"toy_top{k}"].view(np.uint32))
+        assert np.array_equal(ls.view(np.uint32), g[f"toy_ls{k}"].view(np.uint32))
+        norm = np.float32(o.fast_log(N - 1.0)) - np.float32(len(top)) * np.float32(o.fast_log(1 - theta))
+        for l in range(len(top)):
+            assert abs(ls[0] - ls[l]) < 1e-5
+            for n in range(N):
+                assert abs(top[l, n] - top[0, n]) < 1e-5
+                if n != k:
+                    v = (np.float32(o.fast_log(float(top[l, n]))) + ls[l] + norm) / np.float32(rescale)
+                    assert d[k, n] == round(float(v))
+
+
+@pytest.mark.skipif(not ol.ref_available(), reason="compiled reference (oracle/_ref) not present")
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_oracle_matches_compiled_reference_live(seed):
+    seq, r, wb = sy.make_chunk(N=20 + 7 * seed, L=600, W=4, seed=seed, r_mode="skew" if seed % 2 else "flat")
+    for tp, td in ((0.001, 0.001), (0.001, 0.01)):
+        a = ol.oracle().paint_stones(seq, r, tp, td, wb)
+        b = ol.ref().paint_stones(seq, r, tp, td, wb)
+        assert np.array_equal(a, b)
