@@ -1,0 +1,160 @@
+/*
+ * relate_gpu.h -- C ABI of librelate_gpu.so: the MI355X (gfx950) implementation
+ * of Relate's chromosome painting (stepping-stone Li-Stephens forward-backward).
+ *
+ * Everything here is plain C: pointers and sizes, no C++ or torch types.  All
+ * functions return 0 on success and a negative RELATE_E* code on failure
+ * (relate_last_error() gives the text); the library never calls exit() or
+ * aborts, unlike the reference (assert / exit(1), src/data.cpp:15-26).
+ *
+ * Reference citations are relative to the reference tree (tcztzy/relate).
+ */
+#ifndef RELATE_GPU_H
+#define RELATE_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RELATE_OK 0
+#define RELATE_EINVAL (-1)  /* bad argument / malformed input */
+#define RELATE_EIO (-2)     /* file could not be opened, read or written */
+#define RELATE_EGPU (-3)    /* HIP runtime error, or no usable device */
+#define RELATE_ENOMEM (-4)  /* host or device allocation failed */
+#define RELATE_ERANGE (-5)  /* size outside what the kernels support */
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* relate_last_error(void);
+/* Number of HIP devices visible (0 when there is none; never fails). */
+int relate_device_count(void);
+/* Bytes of one stepping-stone record: 56 + 8N (src/fast_painting.cpp:603-615,
+ * src/collapsed_matrix.hpp:240-252). */
+size_t relate_record_bytes(int N);
+
+/* ------------------------------------------------------------------------
+ * 1. Whole-stage drop-in.
+ *
+ * Replaces  int Paint(cxxopts::ParseResult&, int chunk_index)  (pipeline/Paint.cpp:15-91)
+ * and the Rust  Paint::execute  (src/pipelines.rs:133-197), written in the
+ * style of the other stages exported through src/ffi.hpp:8-11 (output
+ * directory, chunk index, nullable pointers for optional values).
+ * Reads <output>/parameters_c<c>.bin and <output>/chunk_<c>.{hap,r}, writes
+ * <output>/chunk_<c>/paint/relate_<w>.bin byte-compatible with the reference.
+ * theta == NULL keeps Data's default 0.001 (src/data.cpp:97); rho == NULL
+ * leaves r unscaled.  device < 0 shards the targets over every visible device.
+ * ------------------------------------------------------------------------ */
+int relate_paint_chunk(const char* output_dir, int chunk_index, const double* theta, const double* rho, int device);
+
+/* ------------------------------------------------------------------------
+ * 2. File-free batched core on host buffers.
+ *
+ * Replaces the loop  for k: FastPainting::PaintSteppingStones(data, window_boundaries, pfiles, k)
+ * (pipeline/Paint.cpp:78-82, src/fast_painting.cpp:634-637) for targets
+ * [k_begin, k_end).  seq is Data::sequence (L x N bytes '0'/'1', row = SNP),
+ * r is Data::r already multiplied by rho, theta_painter builds the painter's
+ * constants (src/fast_painting.hpp:19-45) and theta_data is Data::theta (the
+ * Rust caller passes two different values, src/pipelines.rs:125,181).
+ * out receives W x (k_end-k_begin) records, window-major: record (w,k) at
+ * ((w*(k_end-k_begin)) + (k-k_begin)) * relate_record_bytes(N), i.e. slab w
+ * is the byte range [k_begin*R, k_end*R) of relate_<w>.bin.
+ * ------------------------------------------------------------------------ */
+int relate_paint_stones(int N, int L, const uint8_t* seq, const double* r, double theta_painter, double theta_data,
+                        int num_windows, const int32_t* window_boundaries, int k_begin, int k_end, uint8_t* out,
+                        int device);
+
+/* ------------------------------------------------------------------------
+ * 3. Object mirror of what the reference's FFI binds (src/lib.rs:4-21):
+ *    Data::new2 / Data::SetPainting / FastPainting::new / PaintSteppingStones1.
+ * ------------------------------------------------------------------------ */
+typedef struct relate_data relate_data;
+typedef struct relate_painter relate_painter;
+
+/* Data::Data(6 file names, Ne, mu)  (src/data.cpp:88-99; bound as Data::new2, src/pipelines.rs:161-163).
+ * Only the .hap and .r files are read (src/fast_painting.cpp touches nothing else of Data);
+ * the other four names may be NULL. */
+int relate_data_new(const char* hap, const char* pos, const char* dist, const char* rec, const char* rpos,
+                    const char* state, int Ne, double mu, relate_data** out);
+/* Data::SetPainting(theta, rho)  (src/data.cpp:124-129). */
+int relate_data_set_painting(relate_data* d, double theta, double rho);
+int relate_data_dims(const relate_data* d, int* N, int* L);
+void relate_data_free(relate_data* d);
+
+/* FastPainting::FastPainting(size_t N, double theta)  (src/fast_painting.hpp:19-31). */
+int relate_painter_new(size_t N, double theta, int device, relate_painter** out);
+/* void FastPainting::PaintSteppingStones(const Data&, const char* basename, size_t num_windows,
+ *                                        const int* window_boundaries, const int k) const
+ * (src/fast_painting.cpp:639-652): appends the record of target k to <basename>_<w>.bin for every
+ * window.  The caller invokes k = 0..N-1 in order (src/pipelines.rs:179-194); the first call of a
+ * run of consecutive k paints a batch of targets on the GPU, later calls are served from that batch,
+ * which is kept with the relate_data (the Rust loop builds a new painter per target). */
+int relate_painter_paint_stepping_stones(relate_painter* p, const relate_data* d, const char* basename,
+                                         size_t num_windows, const int32_t* window_boundaries, int k);
+void relate_painter_free(relate_painter* p);
+
+/* ------------------------------------------------------------------------
+ * 4. Device-resident plan: inputs and outputs stay in HBM (what the benchmark
+ *    and the multi-GPU host drive; same algorithm and kernels as 1-3).
+ *    Device pointers are passed as void*; `stream` is a hipStream_t or NULL.
+ * ------------------------------------------------------------------------ */
+typedef struct relate_plan relate_plan;
+
+int relate_plan_create(int device, relate_plan** out);
+void relate_plan_destroy(relate_plan* p);
+/* Kernel choice: variant 1 = hand-scheduled (default), 0 = plain HIP cross-check (small N only);
+ * waves_per_target 0 = automatic, else 1/2/4/8. */
+int relate_plan_configure(relate_plan* p, int variant, int waves_per_target);
+
+/* Packs Data::sequence ('0'/'1' bytes, device pointer d_seq, L x N) into bit rows and their transpose
+ * in HBM ("bit-planes"); replaces ReadSequenceFromBin's in-memory layout (src/data.cpp:541-550).
+ * d_r: L doubles on the device (Data::r times rho).  wb: host array of num_windows+1 ints. */
+int relate_plan_load_device(relate_plan* p, int N, int L, const void* d_seq, const void* d_r, int num_windows,
+                            const int32_t* window_boundaries, void* stream);
+/* Same from host buffers (copies them to the device first). */
+int relate_plan_load_host(relate_plan* p, int N, int L, const uint8_t* seq, const double* r, int num_windows,
+                          const int32_t* window_boundaries);
+/* The packed matrix (rows then transpose, one allocation) for a broadcast to other devices. */
+int relate_plan_packed(relate_plan* p, void** d_packed, size_t* bytes);
+/* Adopts an already packed matrix (as returned by relate_plan_packed on another device, after a broadcast). */
+int relate_plan_load_packed(relate_plan* p, int N, int L, const void* d_packed, size_t bytes, const void* d_r,
+                            int num_windows, const int32_t* window_boundaries, void* stream);
+
+/* Per-target precompute for [k_begin,k_end): derived-site lists, per-gap recombination terms and
+ * window bookkeeping (src/fast_painting.cpp:33-170).  Returns the sum of nd_k in *sum_derived. */
+int relate_plan_prepare(relate_plan* p, double theta_painter, double theta_data, int k_begin, int k_end,
+                        int64_t* sum_derived, void* stream);
+/* Forward + backward recursion of the prepared targets (src/fast_painting.cpp:214-599); writes
+ * num_windows x K records into d_out (device pointer, relate_record_bytes(N)*K*num_windows bytes). */
+int relate_plan_paint(relate_plan* p, void* d_out, void* stream);
+/* Milliseconds of the last pack / prepare / paint, from HIP events on the stream they ran on
+ * (blocks until the paint has finished). */
+int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float* ms_paint);
+/* Geometry the recursion kernel was launched with. */
+int relate_plan_geometry(const relate_plan* p, int* waves_per_target, int* states_per_lane);
+
+/* GPU fast_log (src/fast_log.hpp:6-21) on n floats, host in / host out: used by the parity tests. */
+int relate_fast_log(const float* in, float* out, int n, int device);
+
+/* ------------------------------------------------------------------------
+ * 5. Synthetic chunks (seeded; no counterpart in the reference, which has no
+ *    simulator): haplotypes with linkage disequilibrium from a tree that
+ *    changes by prune-and-regraft moves along the chunk, a 1/i site-frequency
+ *    spectrum, and a recombination map that is flat or has hotspots.
+ *    seq: L*N bytes, r: L doubles, both host buffers supplied by the caller.
+ * ------------------------------------------------------------------------ */
+int relate_synth_chunk(int N, int L, uint64_t seed, int skewed_map, uint8_t* seq, double* r);
+/* Writes <output>/parameters_c<c>.bin and <output>/chunk_<c>.{hap,bp,dist,r,rpos,state} in the
+ * formats of Data::MakeChunks (src/data.cpp:272-286,:496-526). */
+int relate_write_chunk(const char* output_dir, int chunk_index, int N, int L, const uint8_t* seq, const double* r,
+                       int num_windows, const int32_t* window_boundaries);
+/* Window boundaries by the reference's memory rule (src/data.cpp:235-245): a window closes when
+ * sum over its SNPs of derived*(N+1) floats reaches the budget.  wb must hold max_windows+1 ints;
+ * returns the number of windows (>0) or a negative code. */
+int relate_window_boundaries(int N, int L, const uint8_t* seq, double memory_gb, int max_windows, int32_t* wb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELATE_GPU_H */

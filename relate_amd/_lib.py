@@ -1,0 +1,83 @@
+"""ctypes binding of librelate_gpu.so (include/relate_gpu.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "csrc", "librelate_gpu.so")
+
+u8p = C.POINTER(C.c_uint8)
+f64p = C.POINTER(C.c_double)
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+vp = C.c_void_p
+
+
+class RelateError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librelate_gpu error {code}: {msg}")
+        self.code = code
+
+
+def library_path():
+    return _PATH
+
+
+_lib = None
+
+# name -> (restype, argtypes); exactly the functions include/relate_gpu.h declares
+PROTOTYPES = {
+    "relate_last_error": (C.c_char_p, []),
+    "relate_device_count": (C.c_int, []),
+    "relate_record_bytes": (C.c_size_t, [C.c_int]),
+    "relate_paint_chunk": (C.c_int, [C.c_char_p, C.c_int, f64p, f64p, C.c_int]),
+    "relate_paint_stones": (C.c_int, [C.c_int, C.c_int, u8p, f64p, C.c_double, C.c_double, C.c_int, i32p, C.c_int,
+                                      C.c_int, u8p, C.c_int]),
+    "relate_data_new": (C.c_int, [C.c_char_p] * 6 + [C.c_int, C.c_double, C.POINTER(vp)]),
+    "relate_data_set_painting": (C.c_int, [vp, C.c_double, C.c_double]),
+    "relate_data_dims": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "relate_data_free": (None, [vp]),
+    "relate_painter_new": (C.c_int, [C.c_size_t, C.c_double, C.c_int, C.POINTER(vp)]),
+    "relate_painter_paint_stepping_stones": (C.c_int, [vp, vp, C.c_char_p, C.c_size_t, i32p, C.c_int]),
+    "relate_painter_free": (None, [vp]),
+    "relate_plan_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "relate_plan_destroy": (None, [vp]),
+    "relate_plan_configure": (C.c_int, [vp, C.c_int, C.c_int]),
+    "relate_plan_load_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, i32p, vp]),
+    "relate_plan_load_host": (C.c_int, [vp, C.c_int, C.c_int, u8p, f64p, C.c_int, i32p]),
+    "relate_plan_packed": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+    "relate_plan_load_packed": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_int, i32p, vp]),
+    "relate_plan_prepare": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_int, i64p, vp]),
+    "relate_plan_paint": (C.c_int, [vp, vp, vp]),
+    "relate_plan_timings": (C.c_int, [vp, f32p, f32p, f32p]),
+    "relate_plan_geometry": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "relate_fast_log": (C.c_int, [f32p, f32p, C.c_int, C.c_int]),
+    "relate_synth_chunk": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_int, u8p, f64p]),
+    "relate_write_chunk": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, u8p, f64p, C.c_int, i32p]),
+    "relate_window_boundaries": (C.c_int, [C.c_int, C.c_int, u8p, C.c_double, C.c_int, i32p]),
+}
+
+
+def lib():
+    """The loaded library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise RelateError(-3, f"{_PATH} is missing: build it with `make -C relate_amd/csrc` "
+                                  "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RelateError(rc, lib().relate_last_error().decode(errors="replace"))
+
+
+def record_bytes(N):
+    return 56 + 8 * N

@@ -1,0 +1,68 @@
+// Device-side entry points of the painting path (launchers around the gfx950
+// kernels in paint_kernels.hip).  Internal to the library: the public boundary
+// is include/relate_gpu.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace relate {
+
+// Constants of one painter, computed on the host with the host's libm exactly
+// as the reference's constructors do (src/fast_painting.hpp:19-45).
+struct PaintConsts {
+  double Nm1;           // N - 1
+  double prior_mis;     // 1.0*prior_theta + prior_ntheta : alpha_0 of a mismatching state
+  double prior_match;   // prior_ntheta                   : alpha_0 of a matching state
+  double rho_theta;     // theta_ratio + 1.0              : emission ratio of a mismatching state
+  double log_ntheta;    // log(1 - theta_painter)
+  double log_small;     // log(0.01)
+  double log_Nm1;       // log(N - 1)
+  double theta_d;       // Data::theta   (backward pass only)
+  double ntheta_d;      // Data::ntheta
+  double lo, hi;        // rescale thresholds 1e-10, 1e10
+};
+
+struct PaintArgs {
+  const uint64_t* rows;    // [L][row_stride] bit rows: bit (n&63) of word n>>6 = seq[s][n]=='1'
+  int row_stride;          // in 64-bit words, multiple of 8
+  const int32_t* dk;       // flat derived-site lists
+  const double* coef;      // flat r_prob/((1-r_prob)(N-1)) per derived site
+  const double* nx;        // flat nor_x_theta per derived site
+  const int64_t* off;      // [K] start of target t's lists
+  const int32_t* nd;       // [K] number of derived sites
+  const int32_t* bbj;      // [K][W] index into the list where window w's alpha stone is taken
+  const int32_t* bej;      // [K][W] same for the beta stone
+  const int32_t* order;    // [K] launch order (longest target first)
+  const int32_t* wb;       // [W+1] window boundaries (device copy)
+  uint8_t* out;            // [W][K][56+8N] records
+  int N, L, W, k_begin, K;
+  PaintConsts c;
+};
+
+// Geometry of the recursion kernel for N states: G waves per target, each lane
+// of a wave owns MPL states (words wave*MPL .. wave*MPL+MPL-1 of a bit row).
+struct PaintGeometry { int G, MPL; };
+// variant as in launch_paint; MPL == 0 in the result means N is out of range for that variant
+PaintGeometry choose_geometry(int N, int prefer_waves /*0 = default*/, int variant);
+
+int row_stride_words(int N);  // words per packed row
+size_t rows_alloc_bytes(int N, int L);  // allocation size of the packed rows, slack for chunk over-reads included
+int col_stride_words(int L);  // words per packed column
+
+hipError_t launch_pack_rows(const uint8_t* d_seq, uint64_t* d_rows, int N, int L, int row_stride, hipStream_t st);
+hipError_t launch_transpose(const uint64_t* d_rows, uint64_t* d_cols, int N, int L, int row_stride, int col_stride,
+                            hipStream_t st);
+hipError_t launch_count_derived(const uint64_t* d_cols, int col_stride, int L, int k_begin, int K, int32_t* d_nd,
+                                hipStream_t st);
+hipError_t launch_fill_sites(const uint64_t* d_cols, int col_stride, int L, int k_begin, int K, const int64_t* d_off,
+                             int32_t* d_dk, hipStream_t st);
+hipError_t launch_site_terms(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int max_nd,
+                             const double* d_r, int L, const PaintConsts& c, double* d_coef, double* d_nx,
+                             hipStream_t st);
+hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int W,
+                                const int32_t* d_wb, int32_t* d_bbj, int32_t* d_bej, hipStream_t st);
+// variant: 0 = plain HIP recursion, 1 = exec-masked inline-asm recursion
+hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStream_t st);
+hipError_t launch_fast_log(const float* d_in, float* d_out, int n, hipStream_t st);
+
+}  // namespace relate

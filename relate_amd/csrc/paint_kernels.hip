@@ -1,0 +1,502 @@
+// gfx950 (MI355X) kernels of the stepping-stone painting path.
+//
+// Layout in HBM
+//   rows  [L][row_stride] u64 : haplotype matrix, one bit per state; word w of row s
+//                               holds states 64w..64w+63, so a word IS the lane mask of
+//                               the 64 states one wave-instruction updates.
+//   cols  [N][col_stride] u64 : the transpose (bit s&63 of word s>>6 of column k), used
+//                               only to enumerate a target's derived sites.
+//   dk/coef/nx (flat, per target): derived-site list and the two per-gap terms.
+//   out   [W][K][56+8N] bytes : records exactly as they lie in relate_<w>.bin.
+//
+// Recursion kernel: one workgroup of G waves owns one target; lane l of wave g
+// keeps states 64(g*MPL+i)+l, i < MPL, as doubles in VGPRs for the whole pass.
+// The per-site normaliser is a DPP row reduction + 4 readlanes (+ one LDS
+// exchange when G > 1).  No MFMA: the recurrence is a rank-1 update plus a
+// diagonal scaling per site, not a contraction.
+//
+// Compiled with -ffp-contract=off: every product and sum rounds on its own,
+// as in the reference's scalar code; fused operations appear only where written.
+#include "paint_device.hpp"
+#include "paint_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace relate {
+
+namespace {
+
+using namespace dev;
+
+__global__ void fast_log_kernel(const float* __restrict__ in, float* __restrict__ out, int n)
+{
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fast_log_dev(in[i]);
+}
+
+// ------------------------------------------------------------------ packing
+// chunk_<c>.hap rows ('0'/'1' bytes, src/data.cpp:541-550) -> bit rows.  One wave
+// per output word: 64 coalesced bytes in, one ballot, one 8-byte store.
+__global__ void __launch_bounds__(256) pack_rows_kernel(const uint8_t* __restrict__ seq, uint64_t* __restrict__ rows,
+                                                        int N, int L, int row_stride)
+{
+  const int lane = lane_id();
+  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  const long long total = (long long)L * row_stride;
+  for (long long idx = wave; idx < total; idx += nwaves) {
+    const long long s = idx / row_stride;
+    const int n = (int)(idx - s * row_stride) * 64 + lane;
+    const bool one = (n < N) && seq[s * N + n] == (uint8_t)'1';
+    const unsigned long long m = __ballot(one);
+    if (lane == 0) rows[idx] = m;
+  }
+}
+
+// 64x64 bit-tile transpose: lane l reads word `wi` of row 64*sblk+l; ballot b
+// collects bit b of all 64 rows = 64 consecutive sites of haplotype 64*wi+b.
+__global__ void __launch_bounds__(256) transpose_kernel(const uint64_t* __restrict__ rows, uint64_t* __restrict__ cols,
+                                                        int N, int L, int row_stride, int col_stride)
+{
+  const int lane = lane_id();
+  const int wi = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (wi * 64 >= N) return;
+  const int sblk = blockIdx.x;
+  const long long s = (long long)sblk * 64 + lane;
+  const uint64_t x = (s < L) ? rows[s * row_stride + wi] : 0ull;
+  uint64_t mine = 0;
+#pragma unroll
+  for (int b = 0; b < 64; b++) {
+    const unsigned long long m = __ballot((x >> b) & 1ull);
+    if (lane == b) mine = m;
+  }
+  const int n = wi * 64 + lane;
+  if (n < N) cols[(long long)n * col_stride + sblk] = mine;
+}
+
+// Column word sw of target k with the forced sites applied: site 0 and site
+// L-1 count as derived whatever the haplotype carries, sites past L-1 do not
+// exist (src/fast_painting.cpp:65,69,106: `snp != last_snp` ends every skip).
+__device__ __forceinline__ uint64_t derived_word(const uint64_t* __restrict__ col, int sw, int L)
+{
+  const int last = L - 1, lw = last >> 6, lb = last & 63;
+  uint64_t x = 0;
+  if (sw <= lw) x = col[sw];
+  if (sw == lw) x = (x & ((1ull << lb) - 1ull)) | (1ull << lb);
+  if (sw == 0) x |= 1ull;
+  if (sw > lw) x = 0;
+  return x;
+}
+
+__global__ void __launch_bounds__(256) count_derived_kernel(const uint64_t* __restrict__ cols, int col_stride, int L,
+                                                            int k_begin, int K, int32_t* __restrict__ nd)
+{
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= K) return;
+  const uint64_t* col = cols + (long long)(k_begin + t) * col_stride;
+  int cnt = 0;
+  for (int sw = lane_id(); sw < col_stride; sw += 64) cnt += __popcll(derived_word(col, sw, L));
+  cnt = wave_sum_int(cnt);
+  if (lane_id() == 0) nd[t] = cnt;
+}
+
+// One wave per target; each pass covers 64 column words (4096 sites): lane l
+// expands the set bits of its word after an exclusive prefix sum of popcounts.
+__global__ void __launch_bounds__(256) fill_sites_kernel(const uint64_t* __restrict__ cols, int col_stride, int L,
+                                                         int k_begin, int K, const int64_t* __restrict__ off,
+                                                         int32_t* __restrict__ dk)
+{
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= K) return;
+  const int lane = lane_id();
+  const uint64_t* col = cols + (long long)(k_begin + t) * col_stride;
+  int32_t* dst = dk + off[t];
+  int base = 0;
+  for (int sw0 = 0; sw0 < col_stride; sw0 += 64) {
+    const int sw = sw0 + lane;
+    uint64_t x = (sw < col_stride) ? derived_word(col, sw, L) : 0ull;
+    const int c = __popcll(x);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    int pos = base + incl - c;
+    while (x) {
+      const int b = __ffsll((long long)x) - 1;
+      dst[pos++] = sw * 64 + b;
+      x &= x - 1;
+    }
+    base += __shfl(incl, 63, 64);
+  }
+}
+
+// Per-gap terms (src/fast_painting.cpp:66-157): the recombination distance of
+// gap j is accumulated left to right starting from r[dk[j]]; the last entry is
+// r[L-1] alone.  Stored as coef = r_prob/((1-r_prob)(N-1)), the only form the
+// recursion uses (:274,:365,:469,:569), and nor_x_theta.
+__global__ void __launch_bounds__(256) site_terms_kernel(const int32_t* __restrict__ dk, const int64_t* __restrict__ off,
+                                                         const int32_t* __restrict__ nd, const double* __restrict__ r,
+                                                         double log_ntheta, double log_small, double Nm1,
+                                                         double* __restrict__ coef, double* __restrict__ nx)
+{
+  const int t = blockIdx.y;
+  const int n = nd[t];
+  const long long o = off[t];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int s0 = dk[o + j];
+    const int s1 = (j + 1 < n) ? dk[o + j + 1] : s0 + 1;
+    double rsum = r[s0];
+    for (int s = s0 + 1; s < s1; s++) rsum += r[s];
+    double nxv = -rsum + log_ntheta;
+    double rp = 1.0 - exp(-rsum);
+    if (rp > 0.99) {
+      rp = 0.99;
+      nxv = log_small + log_ntheta;
+    }
+    coef[o + j] = rp / ((1.0 - rp) * Nm1);
+    nx[o + j] = nxv;
+  }
+}
+
+// Window bookkeeping (src/fast_painting.cpp:33-45,:73-82,:111-120,:163-166) in
+// closed form: for the edge e = wb[w] (w >= 1), q = first derived site >= e
+// closes window w-1 and its predecessor opens window w.
+__global__ void window_stones_kernel(const int32_t* __restrict__ dk, const int64_t* __restrict__ off,
+                                     const int32_t* __restrict__ nd, int K, int W, const int32_t* __restrict__ wb,
+                                     int32_t* __restrict__ bbj, int32_t* __restrict__ bej)
+{
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)K * W) return;
+  const int t = (int)(idx / W), w = (int)(idx - (long long)t * W);
+  const int32_t* d = dk + off[t];
+  const int n = nd[t];
+  if (w == 0) bbj[(long long)t * W] = 0;
+  if (w == W - 1) bej[(long long)t * W + w] = n - 1;
+  if (w >= 1) {
+    const int e = wb[w];
+    int lo = 0, hi = n - 1;  // d[n-1] = L-1 >= e always
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (d[mid] >= e) hi = mid;
+      else lo = mid + 1;
+    }
+    bej[(long long)t * W + w - 1] = lo;
+    bbj[(long long)t * W + w] = lo - 1;
+  }
+}
+
+// Plain-HIP recursion (variant 0).
+template <int MPL, int G>
+__global__ void __launch_bounds__(64 * G) paint_kernel(
+    const uint64_t* __restrict__ rows, const int32_t* __restrict__ dk_all, const double* __restrict__ coef_all,
+    const double* __restrict__ nx_all, const int64_t* __restrict__ off, const int32_t* __restrict__ nd_all,
+    const int32_t* __restrict__ bbj_all, const int32_t* __restrict__ bej_all, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ wb, uint8_t* __restrict__ out, const Scal p)
+{
+  __shared__ double red[2][G];
+  int slot = 0;
+  const int t = order[blockIdx.x];
+  const int k = p.k_begin + t;
+  const int lane = lane_id();
+  const int wbase = (threadIdx.x >> 6) * MPL;
+  const int N = p.N, W = p.W, stride = p.row_stride;
+  const int nd = nd_all[t];
+  const int32_t* __restrict__ dk = dk_all + off[t];
+  const double* __restrict__ coef = coef_all + off[t];
+  const double* __restrict__ nx = nx_all + off[t];
+  const int32_t* __restrict__ bbj = bbj_all + (long long)t * W;
+  const int32_t* __restrict__ bej = bej_all + (long long)t * W;
+  const size_t R = 56 + (size_t)8 * N;
+  const int kw = k >> 6, kb = k & 63;
+  const bool first_thread = threadIdx.x == 0;
+  const PaintConsts& c = p.c;
+
+  double a[MPL];
+
+  // ---------------- forward (src/fast_painting.cpp:214-408) ----------------
+  {
+    const uint64_t* row = rows;  // site 0
+    const bool sk = (row_word(row, kw, stride) >> kb) & 1ull;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < MPL; i++) {
+      const int wi = wbase + i;
+      const uint64_t w = row_word(row, wi, stride);
+      const uint64_t vm = valid_mask(wi, N, k);
+      const uint64_t mm = sk ? (~w & vm) : 0ull;
+      const bool v = (vm >> lane) & 1ull, m = (mm >> lane) & 1ull;
+      a[i] = v ? (m ? c.prior_mis : c.prior_match) : 0.0;
+      acc += a[i];
+    }
+    double S = block_sum<G>(acc, red, slot);
+    double ls = 0.0;
+    int wcur = 0;
+    auto emit = [&](int j, int s) {
+      while (wcur < W && bbj[wcur] == j) {
+        uint8_t* rec = out + ((size_t)wcur * p.K + t) * R;
+        if (first_thread) {
+          put_u32(rec, (uint32_t)wb[wcur]);
+          put_u32(rec + 4, (uint32_t)(wb[wcur + 1] - 1));
+          put_block_header(rec + 8, N, s, (float)ls);
+        }
+        store_payload<MPL>(reinterpret_cast<float*>(rec + 32), a, wbase, N);
+        wcur++;
+      }
+    };
+    emit(0, 0);
+    double rx = coef[0] * S;
+    for (int j = 1; j < nd; j++) {
+      const int s = dk[j];
+      row = rows + (size_t)s * stride;
+      const bool skj = (row_word(row, kw, stride) >> kb) & 1ull;
+      ls += nx[j - 1];
+      acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < MPL; i++) {
+        const int wi = wbase + i;
+        const uint64_t w = row_word(row, wi, stride);
+        const uint64_t vm = valid_mask(wi, N, k);
+        const uint64_t mm = skj ? (~w & vm) : 0ull;
+        const bool v = (vm >> lane) & 1ull, m = (mm >> lane) & 1ull;
+        double x = a[i] + rx;
+        const double xm = x * c.rho_theta;
+        x = m ? xm : x;
+        a[i] = v ? x : 0.0;
+        acc += a[i];
+      }
+      S = block_sum<G>(acc, red, slot);
+      if (S < c.lo || S > c.hi) {
+#pragma unroll
+        for (int i = 0; i < MPL; i++) a[i] = a[i] / S;
+        ls += log(S);
+        S = 1.0;
+      }
+      rx = S * coef[j];
+      emit(j, s);
+    }
+  }
+
+  // ---------------- backward (src/fast_painting.cpp:410-599) ----------------
+  {
+    double ls = c.log_Nm1 - (double)nd * c.log_ntheta;
+    const uint64_t* row_next = rows + (size_t)(p.L - 1) * stride;  // row of the site handled one step earlier
+    bool sk_next = (row_word(row_next, kw, stride) >> kb) & 1ull;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < MPL; i++) {
+      const int wi = wbase + i;
+      const uint64_t w = row_word(row_next, wi, stride);
+      const uint64_t vm = valid_mask(wi, N, k);
+      const uint64_t mm = sk_next ? (~w & vm) : 0ull;
+      const bool v = (vm >> lane) & 1ull, m = (mm >> lane) & 1ull;
+      a[i] = v ? 1.0 : 0.0;
+      acc += v ? (m ? c.theta_d : c.ntheta_d) : 0.0;
+    }
+    double B = block_sum<G>(acc, red, slot);
+    int wcur = W - 1;
+    // stones taken at the last SNP hold beta = 1 for every state, the target included (:427-432,:447-462)
+    while (wcur >= 0 && bej[wcur] == nd - 1) {
+      uint8_t* rec = out + ((size_t)wcur * p.K + t) * R;
+      if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, p.L - 1, (float)ls);
+      float* dst = reinterpret_cast<float*>(rec + 56 + (size_t)4 * N);
+#pragma unroll
+      for (int i = 0; i < MPL; i++) {
+        const int n = (wbase + i) * 64 + lane;
+        if (n < N) dst[n] = 1.0f;
+      }
+      wcur--;
+    }
+    double rx = coef[nd - 1] * B;
+    for (int j = nd - 2; j >= 0; j--) {
+      const int s = dk[j];
+      const uint64_t* row = rows + (size_t)s * stride;
+      const bool sk = (row_word(row, kw, stride) >> kb) & 1ull;
+      ls += nx[j + 1];
+      const double add_all = rx / c.ntheta_d;
+      const double add_mis = rx / c.theta_d - add_all;
+      acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < MPL; i++) {
+        const int wi = wbase + i;
+        const uint64_t vm = valid_mask(wi, N, k);
+        const uint64_t wn = row_word(row_next, wi, stride);
+        const uint64_t wc = row_word(row, wi, stride);
+        const uint64_t mn = sk_next ? (~wn & vm) : 0ull;
+        const uint64_t mc = sk ? (~wc & vm) : 0ull;
+        const bool v = (vm >> lane) & 1ull, m1 = (mn >> lane) & 1ull, m0 = (mc >> lane) & 1ull;
+        double x = a[i];
+        const double x1 = x + add_mis;
+        x = m1 ? x1 : x;
+        x = x + add_all;
+        const double x2 = x * c.rho_theta;
+        x = m1 ? x2 : x;
+        a[i] = v ? x : 0.0;
+        acc += (m0 ? c.theta_d : c.ntheta_d) * a[i];
+      }
+      B = block_sum<G>(acc, red, slot);
+      if (B < c.lo || B > c.hi) {
+#pragma unroll
+        for (int i = 0; i < MPL; i++) a[i] = a[i] / B;
+        ls += (double)fast_log_dev((float)B);  // float approximation on this side (:562)
+        B = 1.0;
+      }
+      rx = B * coef[j];
+      while (wcur >= 0 && bej[wcur] == j) {
+        uint8_t* rec = out + ((size_t)wcur * p.K + t) * R;
+        if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, s, (float)ls);
+        store_payload<MPL>(reinterpret_cast<float*>(rec + 56 + (size_t)4 * N), a, wbase, N);
+        wcur--;
+      }
+      row_next = row;
+      sk_next = sk;
+    }
+  }
+}
+
+
+template <int MPL, int G>
+hipError_t launch_plain_t(const PaintArgs& a, hipStream_t st)
+{
+  Scal s;
+  s.row_stride = a.row_stride;
+  s.N = a.N;
+  s.L = a.L;
+  s.W = a.W;
+  s.k_begin = a.k_begin;
+  s.K = a.K;
+  s.c = a.c;
+  hipLaunchKernelGGL((paint_kernel<MPL, G>), dim3(a.K), dim3(64 * G), 0, st, a.rows, a.dk, a.coef, a.nx, a.off, a.nd,
+                     a.bbj, a.bej, a.order, a.wb, a.out, s);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side
+int row_stride_words(int N) { return ((N + 63) / 64 + 7) / 8 * 8; }
+int col_stride_words(int L) { return (L + 63) / 64; }
+
+// Plain-HIP kernels exist for a few small geometries only (cross-check of the hand-scheduled ones).
+static const int kMplPlain[] = {1, 4, 16};
+static const int kMplHand[] = {8, 16, 24, 32, 40, 48, 64, 80};
+
+PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
+{
+  const int M = (N + 63) / 64;
+  const int* tab = variant == 0 ? kMplPlain : kMplHand;
+  const int ntab = variant == 0 ? 3 : 8;
+  const int maxG = variant == 0 ? 4 : 8;
+  const int mpl_max = tab[ntab - 1];
+  int G = 1;
+  if (prefer_waves == 2 || prefer_waves == 4 || prefer_waves == 8) G = prefer_waves;
+  if (G > maxG) G = maxG;
+  while (G < maxG && (M + G - 1) / G > mpl_max) G *= 2;
+  const int need = (M + G - 1) / G;
+  int MPL = 0;
+  for (int i = 0; i < ntab; i++)
+    if (tab[i] >= need) {
+      MPL = tab[i];
+      break;
+    }
+  if (variant != 0 && G == 8 && MPL == 80) MPL = 0;  // stone staging would exceed the LDS of a CU
+  return {G, MPL};  // MPL == 0: N too large for this variant
+}
+
+// Bytes to allocate for the packed rows: the recursion kernel fetches whole 4-word chunks for all
+// G*MPL words of a wave group, which may run past the end of the last row.
+size_t rows_alloc_bytes(int N, int L) { return ((size_t)L * row_stride_words(N) + 8 * 80 + 64) * sizeof(uint64_t); }
+
+hipError_t launch_pack_rows(const uint8_t* d_seq, uint64_t* d_rows, int N, int L, int row_stride, hipStream_t st)
+{
+  const long long words = (long long)L * row_stride;
+  long long blocks = (words + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_seq, d_rows, N, L, row_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_transpose(const uint64_t* d_rows, uint64_t* d_cols, int N, int L, int row_stride, int col_stride,
+                            hipStream_t st)
+{
+  const int M = (N + 63) / 64;
+  hipLaunchKernelGGL(transpose_kernel, dim3(col_stride, (M + 3) / 4), dim3(256), 0, st, d_rows, d_cols, N, L,
+                     row_stride, col_stride);
+  return hipGetLastError();
+}
+
+hipError_t launch_count_derived(const uint64_t* d_cols, int col_stride, int L, int k_begin, int K, int32_t* d_nd,
+                                hipStream_t st)
+{
+  hipLaunchKernelGGL(count_derived_kernel, dim3((K + 3) / 4), dim3(256), 0, st, d_cols, col_stride, L, k_begin, K, d_nd);
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_sites(const uint64_t* d_cols, int col_stride, int L, int k_begin, int K, const int64_t* d_off,
+                             int32_t* d_dk, hipStream_t st)
+{
+  hipLaunchKernelGGL(fill_sites_kernel, dim3((K + 3) / 4), dim3(256), 0, st, d_cols, col_stride, L, k_begin, K, d_off,
+                     d_dk);
+  return hipGetLastError();
+}
+
+hipError_t launch_site_terms(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int max_nd,
+                             const double* d_r, int L, const PaintConsts& c, double* d_coef, double* d_nx,
+                             hipStream_t st)
+{
+  (void)L;
+  int bx = (max_nd + 255) / 256;
+  if (bx > 64) bx = 64;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(site_terms_kernel, dim3(bx, K), dim3(256), 0, st, d_dk, d_off, d_nd, d_r, c.log_ntheta,
+                     c.log_small, c.Nm1, d_coef, d_nx);
+  return hipGetLastError();
+}
+
+hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int W,
+                                const int32_t* d_wb, int32_t* d_bbj, int32_t* d_bej, hipStream_t st)
+{
+  const long long n = (long long)K * W;
+  hipLaunchKernelGGL(window_stones_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_dk, d_off, d_nd, K,
+                     W, d_wb, d_bbj, d_bej);
+  return hipGetLastError();
+}
+
+hipError_t launch_fast_log(const float* d_in, float* d_out, int n, hipStream_t st)
+{
+  hipLaunchKernelGGL(fast_log_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_in, d_out, n);
+  return hipGetLastError();
+}
+
+// defined in paint_hand_g*.hip
+hipError_t launch_paint_hand_g1(const PaintArgs& a, int MPL, hipStream_t st);
+hipError_t launch_paint_hand_g2(const PaintArgs& a, int MPL, hipStream_t st);
+hipError_t launch_paint_hand_g4(const PaintArgs& a, int MPL, hipStream_t st);
+hipError_t launch_paint_hand_g8(const PaintArgs& a, int MPL, hipStream_t st);
+
+#define RELATE_PLAIN_CASE(M, GG) \
+  if (g.MPL == M && g.G == GG) return launch_plain_t<M, GG>(a, st);
+
+hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStream_t st)
+{
+  if (g.MPL <= 0 || (long long)g.G * g.MPL * 64 < a.N) return hipErrorInvalidValue;
+  if (a.row_stride % 8 != 0 || (long long)a.row_stride * 64 < a.N || a.K < 1 || a.W < 1 || a.L < 2 || a.N < 2)
+    return hipErrorInvalidValue;
+  if (variant == 0) {
+    RELATE_PLAIN_CASE(1, 1) RELATE_PLAIN_CASE(4, 1) RELATE_PLAIN_CASE(16, 1)
+    RELATE_PLAIN_CASE(1, 2) RELATE_PLAIN_CASE(4, 2) RELATE_PLAIN_CASE(16, 2)
+    RELATE_PLAIN_CASE(1, 4) RELATE_PLAIN_CASE(4, 4) RELATE_PLAIN_CASE(16, 4)
+    return hipErrorInvalidValue;
+  }
+  switch (g.G) {
+    case 1: return launch_paint_hand_g1(a, g.MPL, st);
+    case 2: return launch_paint_hand_g2(a, g.MPL, st);
+    case 4: return launch_paint_hand_g4(a, g.MPL, st);
+    case 8: return launch_paint_hand_g8(a, g.MPL, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace relate

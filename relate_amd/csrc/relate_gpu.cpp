@@ -1,0 +1,741 @@
+// Host side of librelate_gpu.so: the C ABI of include/relate_gpu.h over the
+// gfx950 kernels (paint_kernels.hip, paint_hand_g*.hip).  Mirrors, for the
+// painting path only, what pipeline/Paint.cpp and src/data.cpp do on the host:
+// reading the chunk files, the loop over targets, and the record files.
+//
+// There is no CPU fallback anywhere in this file: without a HIP device every
+// compute entry point fails with RELATE_EGPU.
+#include "../../include/relate_gpu.h"
+
+#include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "chunk_io.hpp"
+#include "paint_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(RELATE_EGPU, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// Device buffer that grows and is reused between calls.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes)
+  {
+    if (bytes <= cap) return RELATE_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    // grow with some headroom so that successive batches of slightly different size do not reallocate
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      p = nullptr;
+      return fail(RELATE_ENOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed");
+    }
+    cap = want;
+    return RELATE_OK;
+  }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const
+  {
+    return static_cast<T*>(p);
+  }
+};
+
+relate::PaintConsts make_consts(int N, double theta_p, double theta_d)
+{
+  // src/fast_painting.hpp:19-45, with the host's libm as in the reference
+  relate::PaintConsts c;
+  const double ntheta = 1.0 - theta_p;
+  c.Nm1 = (double)N - 1.0;
+  const double prior_theta = theta_p / c.Nm1 - ntheta / c.Nm1;
+  const double prior_ntheta = ntheta / c.Nm1;
+  const double theta_ratio = theta_p / ntheta - 1.0;
+  c.prior_mis = 1.0 * prior_theta + prior_ntheta;
+  c.prior_match = prior_ntheta;
+  c.rho_theta = 1.0 * theta_ratio + 1.0;
+  c.log_ntheta = std::log(ntheta);
+  c.log_small = std::log(0.01);
+  c.log_Nm1 = std::log(c.Nm1);
+  c.theta_d = theta_d;
+  c.ntheta_d = 1.0 - theta_d;
+  c.lo = 1e-10;
+  c.hi = 1.0 / c.lo;
+  return c;
+}
+
+int check_windows(int L, int W, const int32_t* wb)
+{
+  if (W < 1 || !wb) return fail(RELATE_EINVAL, "need at least one window");
+  if (wb[W] != L) return fail(RELATE_EINVAL, "last window boundary must equal L (src/fast_painting.cpp:42)");
+  if (wb[0] < 0) return fail(RELATE_EINVAL, "negative window boundary");
+  for (int w = 1; w <= W; w++) {
+    if (wb[w] < wb[w - 1]) return fail(RELATE_EINVAL, "window boundaries must not decrease");
+    if (wb[w] < 1) return fail(RELATE_EINVAL, "window boundaries after the first must be positive");
+  }
+  return RELATE_OK;
+}
+
+}  // namespace
+
+struct relate_plan {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  int variant = 1, prefer_waves = 0;
+  // chunk
+  int N = 0, L = 0, W = 0;
+  int row_stride = 0, col_stride = 0;
+  DevBuf packed;  // rows, then cols
+  bool packed_borrowed = false;
+  const uint64_t* d_rows = nullptr;
+  const uint64_t* d_cols = nullptr;
+  DevBuf seq_own, r_own, wb_dev;
+  const double* d_r = nullptr;
+  std::vector<int32_t> wb;
+  // prepared targets
+  int k_begin = 0, K = 0;
+  double theta_p = 0, theta_d = 0;
+  DevBuf nd, off, dk, coef, nx, bbj, bej, order;
+  std::vector<int32_t> h_nd;
+  std::vector<int64_t> h_off;
+  int64_t sum_nd = 0;
+  relate::PaintGeometry geo{0, 0};
+  // timing
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool have_pack = false, have_prepare = false, have_paint = false;
+
+  hipStream_t pick(void* s) const { return s ? static_cast<hipStream_t>(s) : own_stream; }
+};
+
+namespace {
+
+int plan_set_chunk(relate_plan* p, int N, int L, int W, const int32_t* wb, hipStream_t st)
+{
+  if (N < 2 || L < 2) return fail(RELATE_EINVAL, "need N >= 2 haplotypes and L >= 2 SNPs");
+  if (int rc = check_windows(L, W, wb)) return rc;
+  p->N = N;
+  p->L = L;
+  p->W = W;
+  p->row_stride = relate::row_stride_words(N);
+  p->col_stride = relate::col_stride_words(L);
+  p->wb.assign(wb, wb + W + 1);
+  if (int rc = p->wb_dev.reserve(sizeof(int32_t) * (W + 1))) return rc;
+  HIP_TRY(hipMemcpyAsync(p->wb_dev.p, p->wb.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice, st));
+  p->K = 0;
+  return RELATE_OK;
+}
+
+size_t rows_bytes(const relate_plan* p) { return relate::rows_alloc_bytes(p->N, p->L); }
+size_t cols_bytes(const relate_plan* p) { return ((size_t)p->N * p->col_stride + 64) * sizeof(uint64_t); }
+
+}  // namespace
+
+extern "C" {
+
+const char* relate_last_error(void) { return g_err.c_str(); }
+
+int relate_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+size_t relate_record_bytes(int N) { return 56 + (size_t)8 * N; }
+
+int relate_plan_create(int device, relate_plan** out)
+{
+  if (!out) return fail(RELATE_EINVAL, "null output pointer");
+  *out = nullptr;
+  int n = relate_device_count();
+  if (n <= 0) return fail(RELATE_EGPU, "no HIP device visible: the painting path has no CPU fallback");
+  if (device < 0 || device >= n) return fail(RELATE_EINVAL, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  relate_plan* p = new relate_plan();
+  p->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking);
+  for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&p->ev[i]);
+  if (e != hipSuccess) {
+    relate_plan_destroy(p);
+    return fail(RELATE_EGPU, std::string("stream/event creation: ") + hipGetErrorString(e));
+  }
+  *out = p;
+  return RELATE_OK;
+}
+
+void relate_plan_destroy(relate_plan* p)
+{
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
+  if (!p->packed_borrowed) p->packed.release();
+  for (DevBuf* b : {&p->seq_own, &p->r_own, &p->wb_dev, &p->nd, &p->off, &p->dk, &p->coef, &p->nx, &p->bbj, &p->bej,
+                    &p->order})
+    b->release();
+  for (auto& e : p->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+  delete p;
+}
+
+int relate_plan_configure(relate_plan* p, int variant, int waves_per_target)
+{
+  if (!p) return fail(RELATE_EINVAL, "null plan");
+  if (variant != 0 && variant != 1) return fail(RELATE_EINVAL, "variant must be 0 or 1");
+  if (waves_per_target != 0 && waves_per_target != 1 && waves_per_target != 2 && waves_per_target != 4 &&
+      waves_per_target != 8)
+    return fail(RELATE_EINVAL, "waves_per_target must be 0, 1, 2, 4 or 8");
+  p->variant = variant;
+  p->prefer_waves = waves_per_target;
+  return RELATE_OK;
+}
+
+int relate_plan_load_device(relate_plan* p, int N, int L, const void* d_seq, const void* d_r, int W,
+                            const int32_t* wb, void* stream)
+{
+  if (!p || !d_seq || !d_r) return fail(RELATE_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st = p->pick(stream);
+  if (int rc = plan_set_chunk(p, N, L, W, wb, st)) return rc;
+  if (p->packed_borrowed) {
+    p->packed = DevBuf();
+    p->packed_borrowed = false;
+  }
+  const size_t rb = rows_bytes(p), cb = cols_bytes(p);
+  if (int rc = p->packed.reserve(rb + cb)) return rc;
+  uint64_t* rows = p->packed.as<uint64_t>();
+  uint64_t* cols = reinterpret_cast<uint64_t*>(static_cast<char*>(p->packed.p) + rb);
+  HIP_TRY(hipEventRecord(p->ev[0], st));
+  // slack after the last row is read (never used) by the recursion kernel: keep it defined
+  HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(rows) + (size_t)L * p->row_stride * 8, 0,
+                         rb - (size_t)L * p->row_stride * 8, st));
+  HIP_TRY(relate::launch_pack_rows(static_cast<const uint8_t*>(d_seq), rows, N, L, p->row_stride, st));
+  HIP_TRY(relate::launch_transpose(rows, cols, N, L, p->row_stride, p->col_stride, st));
+  HIP_TRY(hipEventRecord(p->ev[1], st));
+  p->have_pack = true;
+  p->d_rows = rows;
+  p->d_cols = cols;
+  p->d_r = static_cast<const double*>(d_r);
+  return RELATE_OK;
+}
+
+int relate_plan_load_host(relate_plan* p, int N, int L, const uint8_t* seq, const double* r, int W, const int32_t* wb)
+{
+  if (!p || !seq || !r) return fail(RELATE_EINVAL, "null argument");
+  if (N < 2 || L < 2) return fail(RELATE_EINVAL, "need N >= 2 haplotypes and L >= 2 SNPs");
+  HIP_TRY(hipSetDevice(p->device));
+  if (int rc = p->seq_own.reserve((size_t)N * L)) return rc;
+  if (int rc = p->r_own.reserve(sizeof(double) * (size_t)L)) return rc;
+  HIP_TRY(hipMemcpyAsync(p->seq_own.p, seq, (size_t)N * L, hipMemcpyHostToDevice, p->own_stream));
+  HIP_TRY(hipMemcpyAsync(p->r_own.p, r, sizeof(double) * (size_t)L, hipMemcpyHostToDevice, p->own_stream));
+  int rc = relate_plan_load_device(p, N, L, p->seq_own.p, p->r_own.p, W, wb, p->own_stream);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(p->own_stream));
+  p->seq_own.release();  // the byte matrix is 8x the packed one: drop it once packed
+  return RELATE_OK;
+}
+
+int relate_plan_packed(relate_plan* p, void** d_packed, size_t* bytes)
+{
+  if (!p || !d_packed || !bytes) return fail(RELATE_EINVAL, "null argument");
+  if (!p->d_rows) return fail(RELATE_EINVAL, "no chunk loaded");
+  *d_packed = const_cast<uint64_t*>(p->d_rows);
+  *bytes = rows_bytes(p) + cols_bytes(p);
+  return RELATE_OK;
+}
+
+int relate_plan_load_packed(relate_plan* p, int N, int L, const void* d_packed, size_t bytes, const void* d_r, int W,
+                            const int32_t* wb, void* stream)
+{
+  if (!p || !d_packed || !d_r) return fail(RELATE_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st = p->pick(stream);
+  if (int rc = plan_set_chunk(p, N, L, W, wb, st)) return rc;
+  const size_t rb = rows_bytes(p), cb = cols_bytes(p);
+  if (bytes != rb + cb) return fail(RELATE_EINVAL, "packed matrix has the wrong size for N and L");
+  if (!p->packed_borrowed) p->packed.release();
+  p->packed_borrowed = true;
+  p->packed.p = const_cast<void*>(d_packed);
+  p->packed.cap = bytes;
+  p->d_rows = static_cast<const uint64_t*>(d_packed);
+  p->d_cols = reinterpret_cast<const uint64_t*>(static_cast<const char*>(d_packed) + rb);
+  p->d_r = static_cast<const double*>(d_r);
+  p->have_pack = false;
+  return RELATE_OK;
+}
+
+int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_begin, int k_end, int64_t* sum_derived,
+                        void* stream)
+{
+  if (!p) return fail(RELATE_EINVAL, "null plan");
+  if (!p->d_rows) return fail(RELATE_EINVAL, "no chunk loaded");
+  if (k_begin < 0 || k_end > p->N || k_begin >= k_end) return fail(RELATE_EINVAL, "bad target range");
+  if (!(theta_p > 0.0 && theta_p < 1.0 && theta_d > 0.0 && theta_d < 1.0))
+    return fail(RELATE_EINVAL, "theta must lie in (0,1) (src/fast_painting.hpp:23,37)");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st = p->pick(stream);
+  const int K = k_end - k_begin, W = p->W;
+  p->geo = relate::choose_geometry(p->N, p->prefer_waves, p->variant);
+  if (p->geo.MPL <= 0) return fail(RELATE_ERANGE, "N is too large for the selected kernel variant");
+  const relate::PaintConsts c = make_consts(p->N, theta_p, theta_d);
+
+  HIP_TRY(hipEventRecord(p->ev[2], st));
+  if (int rc = p->nd.reserve(sizeof(int32_t) * (size_t)K)) return rc;
+  HIP_TRY(relate::launch_count_derived(p->d_cols, p->col_stride, p->L, k_begin, K, p->nd.as<int32_t>(), st));
+  p->h_nd.resize(K);
+  HIP_TRY(hipMemcpyAsync(p->h_nd.data(), p->nd.p, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  p->h_off.resize(K);
+  int64_t total = 0;
+  int max_nd = 0;
+  for (int t = 0; t < K; t++) {
+    p->h_off[t] = total;
+    total += p->h_nd[t];
+    max_nd = std::max(max_nd, p->h_nd[t]);
+    if (p->h_nd[t] < 2 || p->h_nd[t] > p->L) return fail(RELATE_EGPU, "derived-site count out of range (kernel fault?)");
+  }
+  p->sum_nd = total;
+  // longest targets first: workgroups are handed out in launch order, so the tail of the launch is short
+  std::vector<int32_t> order(K);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p->h_nd[a] > p->h_nd[b]; });
+
+  if (int rc = p->off.reserve(sizeof(int64_t) * (size_t)K)) return rc;
+  if (int rc = p->order.reserve(sizeof(int32_t) * (size_t)K)) return rc;
+  if (int rc = p->dk.reserve(sizeof(int32_t) * (size_t)total)) return rc;
+  if (int rc = p->coef.reserve(sizeof(double) * (size_t)total)) return rc;
+  if (int rc = p->nx.reserve(sizeof(double) * (size_t)total)) return rc;
+  if (int rc = p->bbj.reserve(sizeof(int32_t) * (size_t)K * W)) return rc;
+  if (int rc = p->bej.reserve(sizeof(int32_t) * (size_t)K * W)) return rc;
+  HIP_TRY(hipMemcpyAsync(p->off.p, p->h_off.data(), sizeof(int64_t) * (size_t)K, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(p->order.p, order.data(), sizeof(int32_t) * (size_t)K, hipMemcpyHostToDevice, st));
+  HIP_TRY(relate::launch_fill_sites(p->d_cols, p->col_stride, p->L, k_begin, K, p->off.as<int64_t>(),
+                                    p->dk.as<int32_t>(), st));
+  HIP_TRY(relate::launch_site_terms(p->dk.as<int32_t>(), p->off.as<int64_t>(), p->nd.as<int32_t>(), K, max_nd, p->d_r,
+                                    p->L, c, p->coef.as<double>(), p->nx.as<double>(), st));
+  HIP_TRY(relate::launch_window_stones(p->dk.as<int32_t>(), p->off.as<int64_t>(), p->nd.as<int32_t>(), K, W,
+                                       p->wb_dev.as<int32_t>(), p->bbj.as<int32_t>(), p->bej.as<int32_t>(), st));
+  HIP_TRY(hipEventRecord(p->ev[3], st));
+  // `order` lives on the host stack: the copy above must have left it before we return
+  HIP_TRY(hipStreamSynchronize(st));
+  p->have_prepare = true;
+  p->k_begin = k_begin;
+  p->K = K;
+  p->theta_p = theta_p;
+  p->theta_d = theta_d;
+  if (sum_derived) *sum_derived = total;
+  return RELATE_OK;
+}
+
+int relate_plan_paint(relate_plan* p, void* d_out, void* stream)
+{
+  if (!p || !d_out) return fail(RELATE_EINVAL, "null argument");
+  if (p->K <= 0) return fail(RELATE_EINVAL, "no targets prepared");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st = p->pick(stream);
+  relate::PaintArgs a;
+  a.rows = p->d_rows;
+  a.row_stride = p->row_stride;
+  a.dk = p->dk.as<int32_t>();
+  a.coef = p->coef.as<double>();
+  a.nx = p->nx.as<double>();
+  a.off = p->off.as<int64_t>();
+  a.nd = p->nd.as<int32_t>();
+  a.bbj = p->bbj.as<int32_t>();
+  a.bej = p->bej.as<int32_t>();
+  a.order = p->order.as<int32_t>();
+  a.wb = p->wb_dev.as<int32_t>();
+  a.out = static_cast<uint8_t*>(d_out);
+  a.N = p->N;
+  a.L = p->L;
+  a.W = p->W;
+  a.k_begin = p->k_begin;
+  a.K = p->K;
+  a.c = make_consts(p->N, p->theta_p, p->theta_d);
+  HIP_TRY(hipEventRecord(p->ev[4], st));
+  HIP_TRY(relate::launch_paint(a, p->geo, p->variant, st));
+  HIP_TRY(hipEventRecord(p->ev[5], st));
+  p->have_paint = true;
+  return RELATE_OK;
+}
+
+int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float* ms_paint)
+{
+  if (!p) return fail(RELATE_EINVAL, "null plan");
+  HIP_TRY(hipSetDevice(p->device));
+  float v[3] = {0.f, 0.f, 0.f};
+  const bool have[3] = {p->have_pack, p->have_prepare, p->have_paint};
+  for (int i = 0; i < 3; i++) {
+    if (!have[i]) continue;
+    HIP_TRY(hipEventSynchronize(p->ev[2 * i + 1]));
+    HIP_TRY(hipEventElapsedTime(&v[i], p->ev[2 * i], p->ev[2 * i + 1]));
+  }
+  if (ms_pack) *ms_pack = v[0];
+  if (ms_prepare) *ms_prepare = v[1];
+  if (ms_paint) *ms_paint = v[2];
+  return RELATE_OK;
+}
+
+int relate_plan_geometry(const relate_plan* p, int* waves, int* mpl)
+{
+  if (!p) return fail(RELATE_EINVAL, "null plan");
+  if (waves) *waves = p->geo.G;
+  if (mpl) *mpl = p->geo.MPL;
+  return RELATE_OK;
+}
+
+int relate_fast_log(const float* in, float* out, int n, int device)
+{
+  if (!in || !out || n < 0) return fail(RELATE_EINVAL, "bad argument");
+  if (relate_device_count() <= 0) return fail(RELATE_EGPU, "no HIP device visible");
+  if (n == 0) return RELATE_OK;
+  HIP_TRY(hipSetDevice(device));
+  DevBuf a, b;
+  if (int rc = a.reserve(sizeof(float) * (size_t)n)) return rc;
+  if (int rc = b.reserve(sizeof(float) * (size_t)n)) {
+    a.release();
+    return rc;
+  }
+  hipError_t e = hipMemcpy(a.p, in, sizeof(float) * (size_t)n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = relate::launch_fast_log(a.as<float>(), b.as<float>(), n, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out, b.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost);
+  a.release();
+  b.release();
+  if (e != hipSuccess) return fail(RELATE_EGPU, hipGetErrorString(e));
+  return RELATE_OK;
+}
+
+}  // extern "C"
+
+// --------------------------------------------------------------------------
+// Batched painting of a target range on one device, records handed to a sink.
+// --------------------------------------------------------------------------
+namespace {
+
+// Targets per batch so that the records of one batch stay under `budget` bytes of HBM.
+int batch_targets(int N, int W, size_t budget)
+{
+  const size_t per_target = relate_record_bytes(N) * (size_t)W;
+  size_t k = budget / std::max<size_t>(per_target, 1);
+  if (k < 1) k = 1;
+  if (k > (size_t)N) k = N;
+  return (int)k;
+}
+
+// sink(w, k0, nk, ptr): the records of targets [k0, k0+nk) of window w, contiguous at ptr (host memory).
+template <class Sink>
+int paint_range(relate_plan* p, double theta_p, double theta_d, int k_begin, int k_end, Sink&& sink)
+{
+  const int N = p->N, W = p->W;
+  const size_t R = relate_record_bytes(N);
+  size_t free_b = 0, total_b = 0;
+  HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  // records of a batch + 20 bytes per derived site for the lists; keep half of what is free
+  size_t budget = std::min<size_t>(free_b / 3, (size_t)24 << 30);
+  const int kb = batch_targets(N, W, budget);
+  DevBuf d_out;
+  void* h_out = nullptr;
+  const size_t batch_bytes = R * (size_t)W * (size_t)std::min(kb, k_end - k_begin);
+  if (int rc = d_out.reserve(batch_bytes)) return rc;
+  if (hipHostMalloc(&h_out, batch_bytes, hipHostMallocDefault) != hipSuccess) {
+    d_out.release();
+    return fail(RELATE_ENOMEM, "pinned host allocation failed");
+  }
+  int rc = RELATE_OK;
+  for (int k0 = k_begin; k0 < k_end && rc == RELATE_OK; k0 += kb) {
+    const int k1 = std::min(k_end, k0 + kb), nk = k1 - k0;
+    rc = relate_plan_prepare(p, theta_p, theta_d, k0, k1, nullptr, nullptr);
+    if (rc) break;
+    rc = relate_plan_paint(p, d_out.p, nullptr);
+    if (rc) break;
+    hipError_t e = hipMemcpyAsync(h_out, d_out.p, R * (size_t)W * nk, hipMemcpyDeviceToHost, p->own_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->own_stream);
+    if (e != hipSuccess) {
+      rc = fail(RELATE_EGPU, std::string("painting or copy-back failed: ") + hipGetErrorString(e));
+      break;
+    }
+    for (int w = 0; w < W && rc == RELATE_OK; w++)
+      rc = sink(w, k0, nk, static_cast<const uint8_t*>(h_out) + (size_t)w * nk * R);
+  }
+  (void)hipHostFree(h_out);
+  d_out.release();
+  return rc;
+}
+
+}  // namespace
+
+extern "C" int relate_paint_stones(int N, int L, const uint8_t* seq, const double* r, double theta_p, double theta_d,
+                                   int W, const int32_t* wb, int k_begin, int k_end, uint8_t* out, int device)
+{
+  if (!seq || !r || !wb || !out) return fail(RELATE_EINVAL, "null argument");
+  if (k_begin < 0 || k_end > N || k_begin > k_end) return fail(RELATE_EINVAL, "bad target range");
+  if (k_begin == k_end) return RELATE_OK;
+  relate_plan* p = nullptr;
+  if (int rc = relate_plan_create(device < 0 ? 0 : device, &p)) return rc;
+  int rc = relate_plan_load_host(p, N, L, seq, r, W, wb);
+  const size_t R = relate_record_bytes(N);
+  const size_t K = (size_t)(k_end - k_begin);
+  if (!rc)
+    rc = paint_range(p, theta_p, theta_d, k_begin, k_end, [&](int w, int k0, int nk, const uint8_t* src) {
+      std::memcpy(out + ((size_t)w * K + (size_t)(k0 - k_begin)) * R, src, (size_t)nk * R);
+      return RELATE_OK;
+    });
+  relate_plan_destroy(p);
+  return rc;
+}
+
+// --------------------------------------------------------------------------
+// Data / painter mirror
+// --------------------------------------------------------------------------
+// One painted batch of targets, kept with the data it was computed from: the Rust caller builds a
+// new painter for every target (src/pipelines.rs:179-194), so the painter cannot own it.
+struct StoneCache {
+  double theta_p = 0, theta_d = 0;
+  std::vector<int32_t> wb;
+  int k0 = 0, k1 = 0;
+  std::vector<uint8_t> records;  // [W][k1-k0][R]
+};
+
+struct relate_data {
+  int N = 0, L = 0, Ne = 30000;
+  double mu = 1.25e-8, theta = 0.001, ntheta = 0.999;
+  std::vector<uint8_t> seq;
+  std::vector<double> r;
+  mutable StoneCache cache;
+  mutable std::mutex cache_mutex;
+};
+
+struct relate_painter {
+  size_t N = 0;
+  double theta = 0.001;
+  int device = 0;
+};
+
+extern "C" {
+
+int relate_data_new(const char* hap, const char* pos, const char* dist, const char* rec, const char* rpos,
+                    const char* state, int Ne, double mu, relate_data** out)
+{
+  (void)pos;
+  (void)dist;
+  (void)rpos;
+  (void)state;
+  if (!hap || !rec || !out) return fail(RELATE_EINVAL, "the .hap and .r file names are required");
+  *out = nullptr;
+  relate_data* d = new relate_data();
+  d->Ne = Ne;
+  d->mu = mu;
+  std::string err;
+  if (!relate::io::read_hap(hap, d->N, d->L, d->seq, err) || !relate::io::read_vector(rec, d->r, err)) {
+    delete d;
+    return fail(RELATE_EIO, err);
+  }
+  if ((int)d->r.size() != d->L) {
+    delete d;
+    return fail(RELATE_EINVAL, "the .r file does not have one entry per SNP of the .hap file");
+  }
+  *out = d;
+  return RELATE_OK;
+}
+
+int relate_data_set_painting(relate_data* d, double theta, double rho)
+{
+  if (!d) return fail(RELATE_EINVAL, "null data");
+  if (!(theta > 0.0 && theta < 1.0)) return fail(RELATE_EINVAL, "theta must lie in (0,1)");
+  d->theta = theta;
+  d->ntheta = 1.0 - theta;
+  for (double& v : d->r) v *= rho;
+  d->cache = StoneCache();  // stones painted from the old r and theta are stale
+  return RELATE_OK;
+}
+
+int relate_data_dims(const relate_data* d, int* N, int* L)
+{
+  if (!d) return fail(RELATE_EINVAL, "null data");
+  if (N) *N = d->N;
+  if (L) *L = d->L;
+  return RELATE_OK;
+}
+
+void relate_data_free(relate_data* d) { delete d; }
+
+int relate_painter_new(size_t N, double theta, int device, relate_painter** out)
+{
+  if (!out) return fail(RELATE_EINVAL, "null output pointer");
+  *out = nullptr;
+  if (N < 2) return fail(RELATE_EINVAL, "need at least two haplotypes");
+  if (!(theta > 0.0 && theta < 1.0)) return fail(RELATE_EINVAL, "theta must lie in (0,1) (src/fast_painting.hpp:23)");
+  relate_painter* p = new relate_painter();
+  p->N = N;
+  p->theta = theta;
+  p->device = device < 0 ? 0 : device;
+  *out = p;
+  return RELATE_OK;
+}
+
+void relate_painter_free(relate_painter* p) { delete p; }
+
+int relate_painter_paint_stepping_stones(relate_painter* p, const relate_data* d, const char* basename, size_t W,
+                                         const int32_t* wb, int k)
+{
+  if (!p || !d || !basename || !wb) return fail(RELATE_EINVAL, "null argument");
+  if ((size_t)d->N != p->N) return fail(RELATE_EINVAL, "painter and data disagree on N");
+  if (k < 0 || k >= d->N) return fail(RELATE_EINVAL, "target index out of range");
+  const size_t R = relate_record_bytes(d->N);
+  std::lock_guard<std::mutex> guard(d->cache_mutex);
+  StoneCache& c = d->cache;
+  const bool hit = c.theta_p == p->theta && c.theta_d == d->theta && c.wb.size() == W + 1 &&
+                   std::equal(c.wb.begin(), c.wb.end(), wb) && k >= c.k0 && k < c.k1;
+  if (!hit) {
+    // paint a batch starting at k: the caller walks k upwards (src/pipelines.rs:179-194)
+    const size_t budget = (size_t)2 << 30;
+    const int nk = std::min(d->N - k, batch_targets(d->N, (int)W, budget));
+    std::vector<uint8_t> rec((size_t)W * nk * R);
+    int rc = relate_paint_stones(d->N, d->L, d->seq.data(), d->r.data(), p->theta, d->theta, (int)W, wb, k, k + nk,
+                                 rec.data(), p->device);
+    if (rc) return rc;
+    c.records.swap(rec);
+    c.theta_p = p->theta;
+    c.theta_d = d->theta;
+    c.wb.assign(wb, wb + W + 1);
+    c.k0 = k;
+    c.k1 = k + nk;
+  }
+  const size_t nk = (size_t)(c.k1 - c.k0);
+  for (size_t w = 0; w < W; w++) {
+    char name[1024];
+    snprintf(name, sizeof name, "%s_%i.bin", basename, (int)w);
+    FILE* f = fopen(name, "ab");  // append: the order of the calls is the file format (src/fast_painting.cpp:645)
+    if (!f) return fail(RELATE_EIO, std::string("cannot open ") + name);
+    const uint8_t* src = c.records.data() + (w * nk + (size_t)(k - c.k0)) * R;
+    const bool ok = fwrite(src, 1, R, f) == R;
+    if (fclose(f) != 0 || !ok) return fail(RELATE_EIO, std::string("short write to ") + name);
+  }
+  return RELATE_OK;
+}
+
+// --------------------------------------------------------------------------
+// Whole stage
+// --------------------------------------------------------------------------
+int relate_paint_chunk(const char* output_dir, int chunk_index, const double* theta, const double* rho, int device)
+{
+  if (!output_dir) return fail(RELATE_EINVAL, "null output directory");
+  const int ndev_all = relate_device_count();
+  if (ndev_all <= 0) return fail(RELATE_EGPU, "no HIP device visible: the painting path has no CPU fallback");
+  if (device >= ndev_all) return fail(RELATE_EINVAL, "device index out of range");
+  const std::string dir(output_dir), c = std::to_string(chunk_index);
+  std::string err;
+  int N = 0, L = 0;
+  std::vector<int32_t> wb;
+  if (!relate::io::read_parameters(dir + "/parameters_c" + c + ".bin", N, L, wb, err)) return fail(RELATE_EIO, err);
+  const int W = (int)wb.size() - 1;
+  relate_data* d = nullptr;
+  if (int rc = relate_data_new((dir + "/chunk_" + c + ".hap").c_str(), nullptr, nullptr,
+                               (dir + "/chunk_" + c + ".r").c_str(), nullptr, nullptr, 30000, 1.25e-8, &d))
+    return rc;
+  if (d->N != N || d->L != L) {
+    relate_data_free(d);
+    return fail(RELATE_EINVAL, "parameters_c<c>.bin and chunk_<c>.hap disagree on N or L");
+  }
+  if (theta || rho) {
+    if (int rc = relate_data_set_painting(d, theta ? *theta : d->theta, rho ? *rho : 1.0)) {
+      relate_data_free(d);
+      return rc;
+    }
+  }
+  fprintf(stderr, "---------------------------------------------------------\n");
+  fprintf(stderr, "Painting sequences...\n");  // pipeline/Paint.cpp:60-61
+
+  const std::string chunk_dir = dir + "/chunk_" + c, paint_dir = chunk_dir + "/paint";
+  if ((mkdir(chunk_dir.c_str(), 0777) != 0 && errno != EEXIST) || (mkdir(paint_dir.c_str(), 0777) != 0 && errno != EEXIST)) {
+    relate_data_free(d);
+    return fail(RELATE_EIO, "cannot create " + paint_dir);
+  }
+  const size_t R = relate_record_bytes(N);
+  std::vector<int> fds(W, -1);
+  int rc = RELATE_OK;
+  for (int w = 0; w < W && rc == RELATE_OK; w++) {
+    const std::string name = paint_dir + "/relate_" + std::to_string(w) + ".bin";
+    fds[w] = open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);  // "wb" in pipeline/Paint.cpp:74
+    if (fds[w] < 0) rc = fail(RELATE_EIO, "cannot open " + name);
+  }
+  if (rc == RELATE_OK) {
+    // contiguous target ranges, one per device; every record has a fixed place k*R in its file
+    std::vector<int> devs;
+    if (device >= 0) devs.push_back(device);
+    else
+      for (int i = 0; i < ndev_all; i++) devs.push_back(i);
+    const int nd = (int)std::min<size_t>(devs.size(), (size_t)N);
+    std::vector<int> rcs(nd, RELATE_OK);
+    std::vector<std::string> errs(nd);
+    auto work = [&](int i) {
+      const int k0 = (int)((int64_t)N * i / nd), k1 = (int)((int64_t)N * (i + 1) / nd);
+      relate_plan* p = nullptr;
+      int r = relate_plan_create(devs[i], &p);
+      if (!r) r = relate_plan_load_host(p, N, L, d->seq.data(), d->r.data(), W, wb.data());
+      if (!r)
+        r = paint_range(p, d->theta, d->theta, k0, k1, [&](int w, int kk0, int nk, const uint8_t* src) {
+          size_t done = 0;
+          const size_t total = (size_t)nk * R;
+          while (done < total) {
+            ssize_t n = pwrite(fds[w], src + done, total - done, (off_t)((size_t)kk0 * R + done));
+            if (n <= 0) return fail(RELATE_EIO, "write to relate_" + std::to_string(w) + ".bin failed");
+            done += (size_t)n;
+          }
+          return (int)RELATE_OK;
+        });
+      relate_plan_destroy(p);
+      rcs[i] = r;
+      errs[i] = g_err;
+    };
+    if (nd == 1) {
+      work(0);
+    } else {
+      std::vector<std::thread> th;
+      for (int i = 0; i < nd; i++) th.emplace_back(work, i);
+      for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < nd; i++)
+      if (rcs[i] != RELATE_OK && rc == RELATE_OK) rc = fail(rcs[i], errs[i]);
+  }
+  const std::string saved = g_err;
+  for (int w = 0; w < W; w++)
+    if (fds[w] >= 0 && close(fds[w]) != 0 && rc == RELATE_OK) rc = fail(RELATE_EIO, "close failed");
+  if (rc != RELATE_OK && !saved.empty()) g_err = saved;
+  relate_data_free(d);
+  return rc;
+}
+
+}  // extern "C"

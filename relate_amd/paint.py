@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference's painting interface over the C ABI.
+
+  paint_chunk   <-> int Paint(cxxopts::ParseResult&, int chunk_index)   pipeline/Paint.cpp:15-91
+  paint_stones  <-> the loop over FastPainting::PaintSteppingStones     pipeline/Paint.cpp:78-82
+  Data          <-> Data(6 files), Data::SetPainting                    src/data.cpp:88-99,:124-129
+  FastPainting  <-> FastPainting(N, theta), PaintSteppingStones(basename, ...)  src/fast_painting.cpp:639-652
+  Plan          <-> device-resident plan (inputs/outputs in HBM), used by the benchmark and the multi-GPU host
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, f32p, f64p, i32p, i64p, lib, record_bytes, u8p, vp
+
+
+def _wb(wb):
+    return np.ascontiguousarray(wb, dtype=np.int32)
+
+
+def paint_stones(seq, r, theta_painter, theta_data, wb, k_begin=0, k_end=None, device=0):
+    """Records of targets [k_begin,k_end) as a (W, K, 56+8N) uint8 array (window-major, as in relate_<w>.bin)."""
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    r = np.ascontiguousarray(r, dtype=np.float64)
+    wb = _wb(wb)
+    L, N = seq.shape
+    W = len(wb) - 1
+    k_end = N if k_end is None else k_end
+    out = np.zeros((W, max(k_end - k_begin, 0), record_bytes(N)), dtype=np.uint8)
+    check(lib().relate_paint_stones(N, L, seq.ctypes.data_as(u8p), r.ctypes.data_as(f64p), float(theta_painter),
+                                    float(theta_data), W, wb.ctypes.data_as(i32p), k_begin, k_end,
+                                    out.ctypes.data_as(u8p), device))
+    return out
+
+
+def paint_chunk(output_dir, chunk_index, theta=None, rho=None, device=-1):
+    """Drop-in for the Paint stage: reads <output>/chunk_<c>.*, writes <output>/chunk_<c>/paint/relate_<w>.bin."""
+    t = C.c_double(theta) if theta is not None else None
+    rh = C.c_double(rho) if rho is not None else None
+    check(lib().relate_paint_chunk(str(output_dir).encode(), chunk_index, C.byref(t) if t is not None else None,
+                                   C.byref(rh) if rh is not None else None, device))
+
+
+class Data:
+    """Chunk data as the painting stage sees it (src/data.hpp:29-42)."""
+
+    def __init__(self, hap, pos, dist, rec, rpos, state, Ne=30000, mu=1.25e-8):
+        self._h = vp()
+        enc = lambda s: None if s is None else str(s).encode()  # noqa: E731
+        check(lib().relate_data_new(enc(hap), enc(pos), enc(dist), enc(rec), enc(rpos), enc(state), Ne, mu,
+                                    C.byref(self._h)))
+        n, l = C.c_int(), C.c_int()
+        check(lib().relate_data_dims(self._h, C.byref(n), C.byref(l)))
+        self.N, self.L = n.value, l.value
+
+    def SetPainting(self, theta, rho):
+        check(lib().relate_data_set_painting(self._h, float(theta), float(rho)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().relate_data_free(self._h)
+            self._h = None
+
+
+class FastPainting:
+    """FastPainting(N, theta) as the Rust caller constructs it (src/pipelines.rs:181)."""
+
+    def __init__(self, N, theta=0.001, device=0):
+        self._h = vp()
+        check(lib().relate_painter_new(N, float(theta), device, C.byref(self._h)))
+
+    def PaintSteppingStones(self, data, basename, window_boundaries, k):
+        wb = _wb(window_boundaries)
+        check(lib().relate_painter_paint_stepping_stones(self._h, data._h, str(basename).encode(), len(wb) - 1,
+                                                         wb.ctypes.data_as(i32p), k))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().relate_painter_free(self._h)
+            self._h = None
+
+
+class Plan:
+    """Device-resident painting plan.  Device pointers are plain integers (e.g. torch.Tensor.data_ptr())."""
+
+    def __init__(self, device=0, variant=1, waves_per_target=0):
+        self._h = vp()
+        check(lib().relate_plan_create(device, C.byref(self._h)))
+        check(lib().relate_plan_configure(self._h, variant, waves_per_target))
+        self.N = self.L = self.W = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().relate_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _set(self, N, L, wb):
+        self.N, self.L, self.W = N, L, len(wb) - 1
+
+    def load_device(self, N, L, d_seq, d_r, wb, stream=0):
+        wb = _wb(wb)
+        check(lib().relate_plan_load_device(self._h, N, L, vp(d_seq), vp(d_r), len(wb) - 1, wb.ctypes.data_as(i32p),
+                                            vp(stream)))
+        self._set(N, L, wb)
+
+    def load_host(self, seq, r, wb):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        wb = _wb(wb)
+        L, N = seq.shape
+        check(lib().relate_plan_load_host(self._h, N, L, seq.ctypes.data_as(u8p), r.ctypes.data_as(f64p), len(wb) - 1,
+                                          wb.ctypes.data_as(i32p)))
+        self._set(N, L, wb)
+
+    def packed(self):
+        p, n = vp(), C.c_size_t()
+        check(lib().relate_plan_packed(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def load_packed(self, N, L, d_packed, nbytes, d_r, wb, stream=0):
+        wb = _wb(wb)
+        check(lib().relate_plan_load_packed(self._h, N, L, vp(d_packed), nbytes, vp(d_r), len(wb) - 1,
+                                            wb.ctypes.data_as(i32p), vp(stream)))
+        self._set(N, L, wb)
+
+    def prepare(self, theta_painter, theta_data, k_begin, k_end, stream=0):
+        s = C.c_int64()
+        check(lib().relate_plan_prepare(self._h, float(theta_painter), float(theta_data), k_begin, k_end, C.byref(s),
+                                        vp(stream)))
+        self.K = k_end - k_begin
+        return s.value
+
+    def paint(self, d_out, stream=0):
+        check(lib().relate_plan_paint(self._h, vp(d_out), vp(stream)))
+
+    def out_bytes(self):
+        return self.W * self.K * record_bytes(self.N)
+
+    def timings(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        check(lib().relate_plan_timings(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"pack_ms": a.value, "prepare_ms": b.value, "paint_ms": c.value}
+
+    def geometry(self):
+        g, m = C.c_int(), C.c_int()
+        check(lib().relate_plan_geometry(self._h, C.byref(g), C.byref(m)))
+        return {"waves_per_target": g.value, "states_per_lane": m.value}
+
+
+def fast_log(x, device=0):
+    """GPU fast_log (src/fast_log.hpp:6-21) of a float32 array."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    check(lib().relate_fast_log(x.ctypes.data_as(f32p), y.ctypes.data_as(f32p), x.size, device))
+    return y

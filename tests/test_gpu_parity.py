@@ -1,0 +1,191 @@
+"""GPU parity tests (run on an MI355X with -m gpu): the HIP path, called through the C ABI of
+librelate_gpu.so, against the CPU oracle and the golden vectors of the compiled reference.
+
+Bar: discrete fields of every record bit-exact; alpha/beta/logscale within 1e-5 relative (the
+tolerance the painting is specified to; the recursion runs in FP64 with a different summation order,
+so values agree to ~1e-12 before they are rounded to float and almost all floats are bit-identical)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth_np as sy
+from conftest import GOLDEN_NAMES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5  # relative tolerance on alpha, beta and on the log-probabilities log(value) + logscale
+
+
+def _ra():
+    import relate_amd as ra
+    return ra
+
+
+def compare_records(got, want, N, tag=""):
+    """Discrete fields exact, floats within REL_TOL.  Returns the fraction of floats that are not bit-identical."""
+    assert got.shape == want.shape, tag
+    g, w = ol.decode_records(got), ol.decode_records(want)
+    for key in ("start", "end", "a_rows", "a_cols", "a_snp", "b_rows", "b_cols", "b_snp"):
+        assert np.array_equal(g[key], w[key]), f"{tag}: discrete field {key} differs"
+    nbits = 0
+    total = 0
+    for val, ls in (("alpha", "a_ls"), ("beta", "b_ls")):
+        gv, wv = g[val].astype(np.float64), w[val].astype(np.float64)
+        assert np.isfinite(gv).all(), f"{tag}: non-finite {val}"
+        assert np.array_equal(gv == 0, wv == 0), f"{tag}: zero pattern of {val} differs"
+        rel = np.abs(gv - wv) / np.maximum(np.abs(wv), 1e-300)
+        assert rel.max() <= REL_TOL, f"{tag}: {val} max rel err {rel.max():.3e}"
+        gl, wl = g[ls].astype(np.float64), w[ls].astype(np.float64)
+        assert np.all(np.abs(gl - wl) <= REL_TOL * np.maximum(1.0, np.abs(wl))), f"{tag}: {ls} differs"
+        nz = wv != 0
+        lp_g = np.log(gv[nz]) + np.broadcast_to(gl[..., None], gv.shape)[nz]
+        lp_w = np.log(wv[nz]) + np.broadcast_to(wl[..., None], wv.shape)[nz]
+        assert np.all(np.abs(lp_g - lp_w) <= REL_TOL * np.maximum(1.0, np.abs(lp_w))), f"{tag}: log-prob differs"
+        nbits += np.count_nonzero(g[val].view(np.uint32) != w[val].view(np.uint32))
+        nbits += np.count_nonzero(g[ls].view(np.uint32) != w[ls].view(np.uint32))
+        total += g[val].size + g[ls].size
+    return nbits / total
+
+
+def gpu_paint(seq, r, tp, td, wb, variant=1, waves=0, k_begin=0, k_end=None):
+    """Paint through the device-resident plan API (lets the test pick kernel variant and geometry)."""
+    import torch
+    ra = _ra()
+    L, N = seq.shape
+    k_end = N if k_end is None else k_end
+    plan = ra.Plan(0, variant, waves)
+    plan.load_host(seq, r, wb)
+    plan.prepare(tp, td, k_begin, k_end)
+    out = torch.zeros(plan.out_bytes(), dtype=torch.uint8, device="cuda:0")
+    plan.paint(out.data_ptr())
+    plan.timings()  # waits for the kernel
+    res = out.cpu().numpy().reshape(plan.W, k_end - k_begin, ra.record_bytes(N))
+    plan.close()
+    return res
+
+
+def test_fast_log_bit_exact():
+    from relate_amd.paint import fast_log
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.exp(rng.uniform(np.log(1e-37), np.log(1e37), 200000)).astype(np.float32),
+                        (10.0 ** np.arange(-37, 38)).astype(np.float32),
+                        np.array([1e-10, 1e10, 1.0, 0.5, 2.0, 3.4e38, 1.2e-38], dtype=np.float32)])
+    y = fast_log(x)
+    fl = ol.oracle().fast_log
+    want = np.array([fl(float(v)) for v in x[:20000]], dtype=np.float32)
+    assert np.array_equal(y[:20000].view(np.uint32), want.view(np.uint32))
+    tail = np.array([fl(float(v)) for v in x[-82:]], dtype=np.float32)
+    assert np.array_equal(y[-82:].view(np.uint32), tail.view(np.uint32))
+    assert np.max(np.abs(y.astype(np.float64) - np.log(x.astype(np.float64)))) < 0.007  # test/test_log.cpp:7
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+@pytest.mark.parametrize("variant,waves", [(1, 0), (1, 2), (1, 4), (0, 0), (0, 2)])
+def test_golden_vectors(name, variant, waves):
+    g = load_golden(name)
+    got = gpu_paint(g["seq"], g["r"], g["theta_painter"], g["theta_data"], g["wb"], variant, waves)
+    frac = compare_records(got, g["stones"], g["N"], f"{name} v{variant} g{waves}")
+    assert frac < 1e-3, f"{frac:.2e} of the floats are not bit-identical to the reference"
+
+
+def test_entry_point_host_buffers_matches_golden():
+    """relate_paint_stones (host buffers in, host records out), incl. a sub-range of targets."""
+    ra = _ra()
+    g = load_golden("n70_skew_emptywin")
+    got = ra.paint_stones(g["seq"], g["r"], g["theta_painter"], g["theta_data"], g["wb"])
+    compare_records(got, g["stones"], g["N"], "full")
+    part = ra.paint_stones(g["seq"], g["r"], g["theta_painter"], g["theta_data"], g["wb"], 13, 41)
+    compare_records(part, g["stones"][:, 13:41], g["N"], "range")
+
+
+@pytest.mark.parametrize("N,L,W,seed,mode,tp,td,waves", [
+    (300, 3000, 5, 21, "flat", 0.001, 0.001, 0),
+    (300, 3000, 5, 22, "skew", 0.001, 0.001, 2),     # clamp 0.99, rescale in both directions
+    (513, 1500, 3, 23, "flat", 0.025, 0.025, 0),     # one state in the last word
+    (1000, 1200, 4, 24, "flat", 0.001, 0.01, 0),     # the Rust caller's two thetas
+    (1000, 1200, 4, 25, "skew", 1e-4, 1e-4, 4),
+    (2048, 600, 2, 26, "flat", 0.001, 0.001, 0),     # N a multiple of 64: no partial word
+    (2, 50, 2, 27, "flat", 0.01, 0.01, 0),           # smallest N
+])
+def test_against_oracle(N, L, W, seed, mode, tp, td, waves):
+    seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=seed, r_mode=mode, empty_window=(W >= 3))
+    want = ol.oracle().paint_stones(seq, r, tp, td, wb)
+    got = gpu_paint(seq, r, tp, td, wb, 1, waves)
+    frac = compare_records(got, want, N, f"N={N} L={L}")
+    assert frac < 1e-3
+
+
+def test_full_size_sampled_targets_and_structure():
+    """The benchmark's own workload (N=2000, L=50k): every record's discrete fields are checked against
+    the window table and the derived-site lists; 24 sampled targets are checked against the oracle."""
+    ra = _ra()
+    N, L, W = 2000, 50000, 20
+    seq, r = ra.synth_chunk(N, L, 2)
+    wb = ra.synth.even_windows(L, W)
+    got = gpu_paint(seq, r, 0.001, 0.001, wb)
+    d = ol.decode_records(got)
+    for w in range(W):
+        assert (d["start"][w] == wb[w]).all() and (d["end"][w] == wb[w + 1] - 1).all()
+    assert (d["a_rows"] == 1).all() and (d["b_rows"] == 1).all() and (d["a_cols"] == N).all() and (d["b_cols"] == N).all()
+    assert (d["a_snp"][0] == 0).all() and (d["b_snp"][W - 1] == L - 1).all()
+    # stones sit on derived sites of their target (or the forced ends), on the right side of the window edges
+    der = seq == ord("1")
+    for w in range(1, W):
+        a, b = d["a_snp"][w], d["b_snp"][w - 1]
+        assert (a < wb[w]).all() and (b >= wb[w]).all() and (a < b).all()
+        ks = np.arange(N)
+        assert np.all(der[a, ks] | (a == 0)) and np.all(der[b, ks] | (b == L - 1))
+    ks = np.arange(N)
+    assert (d["alpha"][:, ks, ks] == 0).all()
+    assert np.isfinite(d["alpha"]).all() and np.isfinite(d["beta"]).all() and (d["alpha"] >= 0).all()
+    picks = np.unique(np.concatenate([[0, 1, 63, 64, N - 1, N - 2], np.random.default_rng(5).integers(0, N, 18)]))
+    fracs = []
+    for k in picks:
+        want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb, int(k), int(k) + 1)
+        fracs.append(compare_records(got[:, k:k + 1], want, N, f"target {k}"))
+    assert max(fracs) < 1e-3
+
+
+def test_paint_chunk_files_and_ffi_mirror(tmp_path):
+    """The drop-in boundary: chunk files in, relate_<w>.bin out (whole-stage entry point), and the
+    per-target append interface of the FFI mirror produce the same files as the oracle."""
+    ra = _ra()
+    seq, r, wb = sy.make_chunk(N=90, L=2500, W=5, seed=31, r_mode="flat")
+    out = tmp_path / "out"
+    out.mkdir()
+    ra.write_chunk(out, 0, seq, r, wb)
+    theta, rho = float(np.float32(0.002)), float(np.float32(1.5))
+    ra.paint_chunk(out, 0, theta, rho, device=0)
+    want = ol.oracle().paint_stones(seq, r * rho, theta, theta, wb)
+    R = ra.record_bytes(90)
+    for w in range(5):
+        raw = np.fromfile(out / "chunk_0" / "paint" / f"relate_{w}.bin", dtype=np.uint8)
+        assert raw.size == 90 * R
+        compare_records(raw.reshape(1, 90, R), want[w:w + 1], 90, f"window {w}")
+    # the command-line front end writes the same bytes
+    exe = os.path.join(os.path.dirname(ra.library_path()), "relate-gpu")
+    out2 = tmp_path / "out2"
+    out2.mkdir()
+    ra.write_chunk(out2, 0, seq, r, wb)
+    subprocess.run([exe, "--mode", "Paint", "-o", str(out2), "--chunk_index", "0", "--painting", "0.002,1.5",
+                    "--device", "0"], check=True)
+    for w in range(5):
+        a = (out / "chunk_0" / "paint" / f"relate_{w}.bin").read_bytes()
+        b = (out2 / "chunk_0" / "paint" / f"relate_{w}.bin").read_bytes()
+        assert a == b
+    # FFI mirror: Data::new2 + SetPainting + FastPainting::new(N, theta) + PaintSteppingStones(basename, ..., k)
+    data = ra.Data(out / "chunk_0.hap", out / "chunk_0.bp", out / "chunk_0.dist", out / "chunk_0.r",
+                   out / "chunk_0.rpos", out / "chunk_0.state")
+    data.SetPainting(0.01, 1.0)  # defaults of the Rust front end (src/pipelines.rs:125)
+    base = tmp_path / "relate"
+    for k in range(data.N):
+        # a new painter per target, as the Rust loop does (src/pipelines.rs:181)
+        ra.FastPainting(data.N, 0.001).PaintSteppingStones(data, base, wb, k)
+    want2 = ol.oracle().paint_stones(seq, r, 0.001, 0.01, wb)
+    for w in range(5):
+        raw = np.fromfile(f"{base}_{w}.bin", dtype=np.uint8)
+        assert raw.size == 90 * R
+        compare_records(raw.reshape(1, 90, R), want2[w:w + 1], 90, f"ffi window {w}")
