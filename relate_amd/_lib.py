@@ -65,6 +65,13 @@ def lib():
         if not os.path.exists(_PATH):
             raise RelateError(-3, f"{_PATH} is missing: build it with `make -C relate_amd/csrc` "
                                   "(or __graft_entry__.build()); there is no CPU fallback")
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7; loading it first makes the
+        # library bind to the same copy (same soname) instead of bringing in /opt/rocm's beside it, after
+        # which torch would see no GPU.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_PATH)
         for name, (res, args) in PROTOTYPES.items():
             f = getattr(L, name)

@@ -51,10 +51,15 @@ __device__ __forceinline__ void opaque(uint32_t& x) { asm volatile("" : "+s"(x))
 // Ties the buffer to the wait: every later use of `buf` is ordered after it.
 __device__ __forceinline__ void swait(u64x4& buf) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(buf)); }
 
+// gfx950 needs one wait state between a vector instruction that writes a VGPR and a v_readfirstlane
+// that reads it, and two between a vector instruction that writes an SGPR and a vector instruction
+// that reads it (e.g. the v_writelane of a register spill).  The compiler inserts them between its own
+// instructions but cannot see into an asm statement, so they are part of it: without the leading
+// s_nop the value read is the one the VGPR held before.
 __device__ __forceinline__ uint32_t sgpr32(uint32_t x)
 {
   uint32_t r;
-  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(x));
+  asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(r) : "v"(x));
   return r;
 }
 // A wave-uniform 64-bit value as an SGPR pair.
