@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Benchmark of the Paint hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5]
+
+A step is one complete Paint of one chunk whose inputs (the '0'/'1' haplotype matrix and r) already lie in
+HBM: bit-packing + transpose, per-target precompute, forward/backward recursion of all N targets, records
+written to HBM in their file layout.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every
+rank paints a chunk of its own of the same shape -- chunks are independent, which is also how the reference
+itself is parallelised (one process per --chunk_index, pipeline/Relate.cpp:217-229) -- so the per-GPU work is
+fixed ("weak") and the data path has no collective; the barrier around the timed region runs over RCCL.
+
+Prints ONE JSON line (rank 0).  value = N(N-1)L cell-updates per second summed over all ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (N, L, description)
+    "c2": (2000, 50000, "Paint-only single chunk: 2000 haplotypes x 50k SNPs synthetic"),
+    "c3": (5008, 100000, "1000G-scale: 5008 haplotypes, 100k-SNP synthetic chunk"),
+    "c5": (10000, 50000, "rare-variant-dense: 10k haplotypes x 50k SNPs, skewed recombination map"),
+    "tiny": (256, 4000, "tiny functional check"),
+}
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector FP64 (FMA = 2 flop), spec
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E, spec
+
+
+def cpu_baseline(seq, r, wb, theta, budget_s=15.0):
+    """The reference's own painting code (oracle/_ref, where it was built) or its C restatement
+    (oracle/), timed on one host core on a sample of targets of the same chunk."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    if ol.ref_available():
+        lib, kind = ol.ref(), "reference"
+    else:
+        lib, kind = ol.oracle(), "port"
+    L, N = seq.shape
+    t0 = time.perf_counter()
+    lib.paint_stones(seq, r, theta, theta, wb, 0, 2)
+    per_target = (time.perf_counter() - t0) / 2
+    ks = int(max(4, min(N, budget_s / max(per_target, 1e-6))))
+    ks = min(ks, 256)
+    # targets spread over the panel
+    picks = np.linspace(0, N - 1, ks).astype(int)
+    t0 = time.perf_counter()
+    for k in picks:
+        lib.paint_stones(seq, r, theta, theta, wb, int(k), int(k) + 1)
+    dt = time.perf_counter() - t0
+    return {"value": ks * (N - 1) * L / dt, "unit": "cell-updates/s", "cores": 1, "kind": kind,
+            "sample": f"{ks} of {N} targets of the same chunk, {dt:.1f} s on one core"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--waves", type=int, default=0, help="waves per target (0 = automatic)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--N", type=int, default=0, help="override the number of haplotypes (experiments)")
+    ap.add_argument("--L", type=int, default=0, help="override the number of SNPs (experiments)")
+    args = ap.parse_args()
+
+    import torch
+    import relate_amd as ra
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the painting path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    N, L, desc = WORKLOADS[args.workload]
+    if args.N or args.L:
+        N, L = args.N or N, args.L or L
+        desc = f"custom {N} haplotypes x {L} SNPs"
+    theta = 0.001
+    seq, r = ra.synth_chunk(N, L, seed=2 + rank, skewed_map=(args.workload == "c5"))
+    wb = ra.window_boundaries(seq, memory_gb=5.0)
+    W = len(wb) - 1
+    R = ra.record_bytes(N)
+
+    d_seq = torch.from_numpy(seq).cuda()
+    d_r = torch.from_numpy(r).cuda()
+    d_out = torch.empty(W * N * R, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = ra.Plan(local_rank, 1, args.waves)
+
+    def step():
+        plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, stream)
+        s = plan.prepare(theta, theta, 0, N, stream)
+        plan.paint(d_out.data_ptr(), stream)
+        return s
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sum_nd = 0
+    for _ in range(args.warmup):
+        sum_nd = step()
+    fence()
+    t0 = time.perf_counter()
+    kern = {"pack_ms": 0.0, "prepare_ms": 0.0, "paint_ms": 0.0}
+    for _ in range(args.steps):
+        sum_nd = step()
+        t = plan.timings()  # HIP events recorded on the launch stream around each stage
+        for k in kern:
+            kern[k] += t[k]
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    for k in kern:
+        kern[k] /= max(args.steps, 1)
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        u_nominal = float(N) * (N - 1) * L
+        u_actual = 2.0 * (N - 1) * sum_nd
+        t_paint = kern["paint_ms"] * 1e-3
+        # algorithmic work of the recursion kernel (per launch = one chunk, all N targets)
+        f_alg = 7.0 * (N - 1) * sum_nd                      # FP64 flop: 3 per forward, 4 per backward state update
+        b_alg = (2.0 * ((N + 7) // 8) * sum_nd              # one packed haplotype row per site and pass
+                 + 32.0 * sum_nd                            # per-gap terms, both passes
+                 + float(W) * N * R                         # records written
+                 + ((N + 7) // 8) * L + 8.0 * L)            # inputs read once
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        geo = plan.geometry()
+        out = {
+            "metric": "HMM cell-updates/sec (N^2*L) for Paint",
+            "value": u_nominal * world / dt * args.steps,
+            "unit": "cell-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}", "N": N, "L": L, "windows": W, "theta": theta,
+                       "sum_derived_sites": int(sum_nd), "chunks": world,
+                       "kernel_geometry": geo, "parallelism": f"{world} independent chunk(s), one per GPU"},
+            "actual_state_updates_per_s": u_actual * world / dt * args.steps,
+            "stage_ms": kern,
+            "roofline": {"bound": "valu_fp64", "kernel": "paint_kernel_x (forward+backward recursion)",
+                         "achieved": f_alg / t_paint / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": f_alg / t_paint / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic},
+            "roofline_hbm": {"bound": "hbm", "achieved": b_alg / t_paint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": b_alg / t_paint / 1e9 / HBM_PEAK_GBS, "traffic": traffic},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(seq, r, wb, theta)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

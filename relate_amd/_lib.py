@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "csrc", "librelate_gpu.so")
+# RELATE_GPU_LIB points experiments at another build of the same library (e.g. a timing-only ablation)
+_PATH = os.environ.get("RELATE_GPU_LIB") or os.path.join(_HERE, "csrc", "librelate_gpu.so")
 
 u8p = C.POINTER(C.c_uint8)
 f64p = C.POINTER(C.c_double)

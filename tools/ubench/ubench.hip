@@ -1,0 +1,110 @@
+// Instruction-cost microbenchmarks for gfx950 (development tool, not part of the library).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#include <string>
+
+#define ITERS 4000
+
+template <int P>
+__global__ void k(double* out, const uint64_t* masks, int iters)
+{
+  double a0 = threadIdx.x * 1e-3 + 1.0, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  double rx = 1e-9, rho = 0.999999;
+  float f0 = a0, f1 = a1, f2 = a2, f3 = a3, f4 = a4, f5 = a5, f6 = a6, f7 = a7, fr = 1e-9f;
+  uint64_t m0 = masks[0], m1 = masks[1];
+  uint32_t ml = __builtin_amdgcn_readfirstlane((uint32_t)m0), mh = __builtin_amdgcn_readfirstlane((uint32_t)(m0 >> 32));
+  uint64_t sm0 = ((uint64_t)mh << 32) | ml;
+  ml = __builtin_amdgcn_readfirstlane((uint32_t)m1); mh = __builtin_amdgcn_readfirstlane((uint32_t)(m1 >> 32));
+  uint64_t sm1 = ((uint64_t)mh << 32) | ml;
+  asm volatile("" : "+v"(rx), "+v"(rho), "+v"(fr));
+  for (int it = 0; it < iters; it++) {
+    if constexpr (P == 1) {  // 8 independent v_add_f64
+      asm volatile("v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+                   "v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(rx));
+    } else if constexpr (P == 2) {  // 8 independent v_fma_f64
+      asm volatile("v_fma_f64 %0, %0, %9, %8\n v_fma_f64 %1, %1, %9, %8\n v_fma_f64 %2, %2, %9, %8\n v_fma_f64 %3, %3, %9, %8\n"
+                   "v_fma_f64 %4, %4, %9, %8\n v_fma_f64 %5, %5, %9, %8\n v_fma_f64 %6, %6, %9, %8\n v_fma_f64 %7, %7, %9, %8\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(rx), "v"(rho));
+    } else if constexpr (P == 3) {  // 8 independent v_mul_f64
+      asm volatile("v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %8\n v_mul_f64 %2, %2, %8\n v_mul_f64 %3, %3, %8\n"
+                   "v_mul_f64 %4, %4, %8\n v_mul_f64 %5, %5, %8\n v_mul_f64 %6, %6, %8\n v_mul_f64 %7, %7, %8\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(rho));
+    } else if constexpr (P == 4) {  // 8 independent v_add_f32
+      asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                   "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                   : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(fr));
+    } else if constexpr (P == 5) {  // forward pair block x4 (8 words): 24 f64 + 12 salu, accumulators included
+      double c0 = 0, c1 = 0;
+#define FWD(x, y)                                                                                     \
+      asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n s_andn2_b64 exec, %8, %6\n v_mul_f64 %0, %0, %5\n"  \
+                   "s_andn2_b64 exec, %8, %7\n v_mul_f64 %1, %1, %5\n s_mov_b64 exec, -1\n v_add_f64 %2, %2, %0\n v_add_f64 %3, %3, %1\n" \
+                   : "+v"(x), "+v"(y), "+v"(c0), "+v"(c1) : "v"(rx), "v"(rho), "s"(sm0), "s"(sm1), "s"(sm1) : "scc")
+      FWD(a0, a1); FWD(a2, a3); FWD(a4, a5); FWD(a6, a7);
+      a0 += c0 * 1e-30; a1 += c1 * 1e-30;
+    } else if constexpr (P == 6) {  // same arithmetic without exec toggles
+      double c0 = 0, c1 = 0;
+#define FWDN(x, y)                                                                                    \
+      asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_mul_f64 %0, %0, %5\n"             \
+                   "v_mul_f64 %1, %1, %5\n v_add_f64 %2, %2, %0\n v_add_f64 %3, %3, %1\n"             \
+                   : "+v"(x), "+v"(y), "+v"(c0), "+v"(c1) : "v"(rx), "v"(rho))
+      FWDN(a0, a1); FWDN(a2, a3); FWDN(a4, a5); FWDN(a6, a7);
+      a0 += c0 * 1e-30; a1 += c1 * 1e-30;
+    } else if constexpr (P == 7) {  // 8 v_readlane_b32 + 4 exec writes
+      uint32_t s0, s1, s2, s3, s4, s5, s6, s7;
+      asm volatile("v_readlane_b32 %0, %8, 1\n v_readlane_b32 %1, %8, 2\n v_readlane_b32 %2, %8, 3\n v_readlane_b32 %3, %8, 4\n"
+                   "v_readlane_b32 %4, %8, 5\n v_readlane_b32 %5, %8, 6\n v_readlane_b32 %6, %8, 7\n v_readlane_b32 %7, %8, 8\n"
+                   : "=s"(s0), "=s"(s1), "=s"(s2), "=s"(s3), "=s"(s4), "=s"(s5), "=s"(s6), "=s"(s7) : "v"(f0));
+      asm volatile("" ::"s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(s6), "s"(s7));
+    } else if constexpr (P == 8) {  // 8 dependent v_add_f64 (latency)
+      asm volatile("v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n"
+                   "v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n"
+                   : "+v"(a0) : "v"(rx));
+    } else if constexpr (P == 9) {  // 8 v_cndmask_b32 with SGPR mask
+      asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
+                   "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n"
+                   : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(fr), "s"(sm0));
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;
+}
+
+template <int P>
+void run(const char* name, int instrs, double* d_out, uint64_t* d_masks)
+{
+  for (int waves : {1, 2, 4}) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    dim3 grid(256), block(256 * waves);
+    hipLaunchKernelGGL(k<P>, grid, block, 0, 0, d_out, d_masks, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<P>, grid, block, 0, 0, d_out, d_masks, ITERS);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double cyc = ms * 1e-3 * 2.4e9 / ((double)ITERS * instrs * waves);
+    printf("%-28s waves/SIMD %d  %8.3f ms  %6.2f cycles (at 2.4 GHz) per instr per SIMD\n", name, waves, ms, cyc);
+  }
+}
+
+int main()
+{
+  double* d_out; uint64_t* d_masks;
+  hipMalloc(&d_out, 256 * 1024 * 8);
+  hipMalloc(&d_masks, 16);
+  uint64_t h[2] = {0x5555aaaa3333ccccull, 0x0f0ff0f012345678ull};
+  hipMemcpy(d_masks, h, 16, hipMemcpyHostToDevice);
+  run<1>("v_add_f64 x8 indep", 8, d_out, d_masks);
+  run<2>("v_fma_f64 x8 indep", 8, d_out, d_masks);
+  run<3>("v_mul_f64 x8 indep", 8, d_out, d_masks);
+  run<4>("v_add_f32 x8 indep", 8, d_out, d_masks);
+  run<8>("v_add_f64 x8 dependent", 8, d_out, d_masks);
+  run<5>("fwd pair block (24 f64+12 s)", 36, d_out, d_masks);
+  run<6>("same, no exec toggles (24)", 24, d_out, d_masks);
+  run<7>("v_readlane_b32 x8", 8, d_out, d_masks);
+  run<9>("v_cndmask_b32 sgpr mask x8", 8, d_out, d_masks);
+  return 0;
+}
