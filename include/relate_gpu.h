@@ -115,6 +115,14 @@ int relate_plan_load_device(relate_plan* p, int N, int L, const void* d_seq, con
 /* Same from host buffers (copies them to the device first). */
 int relate_plan_load_host(relate_plan* p, int N, int L, const uint8_t* seq, const double* r, int num_windows,
                           const int32_t* window_boundaries);
+/* Bytes of the packed matrix (bit rows, then their transpose) of an N x L chunk. */
+size_t relate_packed_bytes(int N, int L);
+/* As relate_plan_load_device, but packs into the caller's device buffer d_packed (relate_packed_bytes(N, L)
+ * bytes, 256-byte aligned) and keeps using it: the caller owns it and must keep it alive while the plan
+ * uses the chunk.  This is the buffer a host broadcasts to the other devices (RCCL) before they call
+ * relate_plan_load_packed. */
+int relate_plan_load_device_into(relate_plan* p, int N, int L, const void* d_seq, const void* d_r, int num_windows,
+                                 const int32_t* window_boundaries, void* d_packed, size_t packed_bytes, void* stream);
 /* The packed matrix (rows then transpose, one allocation) for a broadcast to other devices. */
 int relate_plan_packed(relate_plan* p, void** d_packed, size_t* bytes);
 /* Adopts an already packed matrix (as returned by relate_plan_packed on another device, after a broadcast). */

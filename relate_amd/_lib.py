@@ -46,6 +46,8 @@ PROTOTYPES = {
     "relate_plan_configure": (C.c_int, [vp, C.c_int, C.c_int]),
     "relate_plan_load_device": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, i32p, vp]),
     "relate_plan_load_host": (C.c_int, [vp, C.c_int, C.c_int, u8p, f64p, C.c_int, i32p]),
+    "relate_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "relate_plan_load_device_into": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, i32p, vp, C.c_size_t, vp]),
     "relate_plan_packed": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     "relate_plan_load_packed": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_int, i32p, vp]),
     "relate_plan_prepare": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_int, i64p, vp]),

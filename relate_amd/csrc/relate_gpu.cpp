@@ -222,19 +222,34 @@ int relate_plan_configure(relate_plan* p, int variant, int waves_per_target)
   return RELATE_OK;
 }
 
-int relate_plan_load_device(relate_plan* p, int N, int L, const void* d_seq, const void* d_r, int W,
-                            const int32_t* wb, void* stream)
+size_t relate_packed_bytes(int N, int L)
+{
+  if (N < 2 || L < 2) return 0;
+  return relate::rows_alloc_bytes(N, L) + ((size_t)N * relate::col_stride_words(L) + 64) * sizeof(uint64_t);
+}
+
+static int load_device_impl(relate_plan* p, int N, int L, const void* d_seq, const void* d_r, int W, const int32_t* wb,
+                            void* d_packed, size_t packed_bytes, void* stream)
 {
   if (!p || !d_seq || !d_r) return fail(RELATE_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(p->device));
   hipStream_t st = p->pick(stream);
   if (int rc = plan_set_chunk(p, N, L, W, wb, st)) return rc;
-  if (p->packed_borrowed) {
-    p->packed = DevBuf();
-    p->packed_borrowed = false;
-  }
   const size_t rb = rows_bytes(p), cb = cols_bytes(p);
-  if (int rc = p->packed.reserve(rb + cb)) return rc;
+  if (d_packed) {
+    if (packed_bytes != rb + cb) return fail(RELATE_EINVAL, "packed buffer has the wrong size for N and L");
+    if (reinterpret_cast<uintptr_t>(d_packed) % 256 != 0) return fail(RELATE_EINVAL, "packed buffer must be 256-byte aligned");
+    if (!p->packed_borrowed) p->packed.release();
+    p->packed.p = d_packed;
+    p->packed.cap = packed_bytes;
+    p->packed_borrowed = true;
+  } else {
+    if (p->packed_borrowed) {
+      p->packed = DevBuf();
+      p->packed_borrowed = false;
+    }
+    if (int rc = p->packed.reserve(rb + cb)) return rc;
+  }
   uint64_t* rows = p->packed.as<uint64_t>();
   uint64_t* cols = reinterpret_cast<uint64_t*>(static_cast<char*>(p->packed.p) + rb);
   HIP_TRY(hipEventRecord(p->ev[0], st));
@@ -249,6 +264,19 @@ int relate_plan_load_device(relate_plan* p, int N, int L, const void* d_seq, con
   p->d_cols = cols;
   p->d_r = static_cast<const double*>(d_r);
   return RELATE_OK;
+}
+
+int relate_plan_load_device(relate_plan* p, int N, int L, const void* d_seq, const void* d_r, int W,
+                            const int32_t* wb, void* stream)
+{
+  return load_device_impl(p, N, L, d_seq, d_r, W, wb, nullptr, 0, stream);
+}
+
+int relate_plan_load_device_into(relate_plan* p, int N, int L, const void* d_seq, const void* d_r, int W,
+                                 const int32_t* wb, void* d_packed, size_t packed_bytes, void* stream)
+{
+  if (!d_packed) return fail(RELATE_EINVAL, "null packed buffer");
+  return load_device_impl(p, N, L, d_seq, d_r, W, wb, d_packed, packed_bytes, stream);
 }
 
 int relate_plan_load_host(relate_plan* p, int N, int L, const uint8_t* seq, const double* r, int W, const int32_t* wb)

@@ -104,6 +104,13 @@ class Plan:
                                             vp(stream)))
         self._set(N, L, wb)
 
+    def load_device_into(self, N, L, d_seq, d_r, wb, d_packed, nbytes, stream=0):
+        """Packs into a caller-owned device buffer (e.g. a torch tensor that is then broadcast)."""
+        wb = _wb(wb)
+        check(lib().relate_plan_load_device_into(self._h, N, L, vp(d_seq), vp(d_r), len(wb) - 1,
+                                                 wb.ctypes.data_as(i32p), vp(d_packed), nbytes, vp(stream)))
+        self._set(N, L, wb)
+
     def load_host(self, seq, r, wb):
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         r = np.ascontiguousarray(r, dtype=np.float64)
