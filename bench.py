@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--waves", type=int, default=0, help="waves per target (0 = automatic)")
+    ap.add_argument("--variant", type=int, default=2, help="recursion kernel: 2 register-resident, 1 hand-scheduled, 0 plain")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--N", type=int, default=0, help="override the number of haplotypes (experiments)")
     ap.add_argument("--L", type=int, default=0, help="override the number of SNPs (experiments)")
@@ -102,7 +103,7 @@ def main():
     d_r = torch.from_numpy(r).cuda()
     d_out = torch.empty(W * N * R, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    plan = ra.Plan(local_rank, 1, args.waves)
+    plan = ra.Plan(local_rank, args.variant, args.waves)
 
     def step():
         plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, stream)

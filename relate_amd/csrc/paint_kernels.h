@@ -19,6 +19,8 @@ struct PaintConsts {
   double log_Nm1;       // log(N - 1)
   double theta_d;       // Data::theta   (backward pass only)
   double ntheta_d;      // Data::ntheta
+  double inv_theta_d;   // 1 / theta_d, 1 / ntheta_d (the register-resident kernel multiplies where the
+  double inv_ntheta_d;  // reference divides, src/fast_painting.cpp:488-489)
   double lo, hi;        // rescale thresholds 1e-10, 1e10
 };
 
@@ -61,7 +63,7 @@ hipError_t launch_site_terms(const int32_t* d_dk, const int64_t* d_off, const in
                              hipStream_t st);
 hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int W,
                                 const int32_t* d_wb, int32_t* d_bbj, int32_t* d_bej, hipStream_t st);
-// variant: 0 = plain HIP recursion, 1 = exec-masked inline-asm recursion
+// variant: 0 = plain HIP recursion, 1 = exec-masked inline-asm recursion, 2 = register-resident recursion
 hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStream_t st);
 hipError_t launch_fast_log(const float* d_in, float* d_out, int n, hipStream_t st);
 

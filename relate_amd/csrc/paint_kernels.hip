@@ -47,7 +47,9 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const uint8_t* __restric
   for (long long idx = wave; idx < total; idx += nwaves) {
     const long long s = idx / row_stride;
     const int n = (int)(idx - s * row_stride) * 64 + lane;
-    const bool one = (n < N) && seq[s * N + n] == (uint8_t)'1';
+    // lanes past N carry a set bit: a state that never mismatches (the recursion kernels rely on it
+    // or mask those lanes themselves; the transpose never looks at them)
+    const bool one = (n >= N) || seq[s * N + n] == (uint8_t)'1';
     const unsigned long long m = __ballot(one);
     if (lane == 0) rows[idx] = m;
   }
@@ -381,12 +383,13 @@ int col_stride_words(int L) { return (L + 63) / 64; }
 // Plain-HIP kernels exist for a few small geometries only (cross-check of the hand-scheduled ones).
 static const int kMplPlain[] = {1, 4, 16};
 static const int kMplHand[] = {8, 16, 24, 32, 40, 48, 64, 80};
+static const int kMplRegs[] = {4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80};
 
 PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
 {
   const int M = (N + 63) / 64;
-  const int* tab = variant == 0 ? kMplPlain : kMplHand;
-  const int ntab = variant == 0 ? 3 : 8;
+  const int* tab = variant == 0 ? kMplPlain : variant == 1 ? kMplHand : kMplRegs;
+  const int ntab = variant == 0 ? 3 : variant == 1 ? 8 : 15;
   const int maxG = variant == 0 ? 4 : 8;
   const int mpl_max = tab[ntab - 1];
   int G = 1;
@@ -401,6 +404,11 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
       break;
     }
   if (variant != 0 && G == 8 && MPL == 80) MPL = 0;  // stone staging would exceed the LDS of a CU
+  // the register-resident kernel reads G*MPL words of every row and needs the padding bits of all of them
+  if (variant == 2 && MPL > 0 && G * MPL > row_stride_words(N)) {
+    if (prefer_waves > 1) return choose_geometry(N, prefer_waves / 2, variant);
+    MPL = 0;
+  }
   return {G, MPL};  // MPL == 0: N too large for this variant
 }
 
@@ -475,6 +483,11 @@ hipError_t launch_paint_hand_g1(const PaintArgs& a, int MPL, hipStream_t st);
 hipError_t launch_paint_hand_g2(const PaintArgs& a, int MPL, hipStream_t st);
 hipError_t launch_paint_hand_g4(const PaintArgs& a, int MPL, hipStream_t st);
 hipError_t launch_paint_hand_g8(const PaintArgs& a, int MPL, hipStream_t st);
+// defined in paint_regs_g*.hip
+hipError_t launch_paint_regs_g1(const PaintArgs& a, int MPL, hipStream_t st);
+hipError_t launch_paint_regs_g2(const PaintArgs& a, int MPL, hipStream_t st);
+hipError_t launch_paint_regs_g4(const PaintArgs& a, int MPL, hipStream_t st);
+hipError_t launch_paint_regs_g8(const PaintArgs& a, int MPL, hipStream_t st);
 
 #define RELATE_PLAIN_CASE(M, GG) \
   if (g.MPL == M && g.G == GG) return launch_plain_t<M, GG>(a, st);
@@ -489,6 +502,16 @@ hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStr
     RELATE_PLAIN_CASE(1, 2) RELATE_PLAIN_CASE(4, 2) RELATE_PLAIN_CASE(16, 2)
     RELATE_PLAIN_CASE(1, 4) RELATE_PLAIN_CASE(4, 4) RELATE_PLAIN_CASE(16, 4)
     return hipErrorInvalidValue;
+  }
+  if (variant == 2) {
+    if (g.G * g.MPL > a.row_stride) return hipErrorInvalidValue;
+    switch (g.G) {
+      case 1: return launch_paint_regs_g1(a, g.MPL, st);
+      case 2: return launch_paint_regs_g2(a, g.MPL, st);
+      case 4: return launch_paint_regs_g4(a, g.MPL, st);
+      case 8: return launch_paint_regs_g8(a, g.MPL, st);
+      default: return hipErrorInvalidValue;
+    }
   }
   switch (g.G) {
     case 1: return launch_paint_hand_g1(a, g.MPL, st);

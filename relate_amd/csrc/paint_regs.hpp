@@ -1,0 +1,663 @@
+// Register-resident gfx950 recursion kernel of the stepping-stone painting
+// (forward and backward Li-Stephens passes of one target per workgroup).
+//
+// The states of a wave (MPL doubles per lane) live in a fixed block of VGPRs that the compiler never
+// sees: the kernel is compiled with amdgpu_num_vgpr / amdgpu_num_sgpr, which keeps the register
+// allocator below v[kCV] / s[kCS], and everything above is addressed by number from inline asm.
+// Hence no spills, no copies at control-flow joins, and the sweep over the states is straight-line
+// code:
+//   forward   a' = (a + rx) * (mismatch ? rho : 1)           add, masked mul, accumulate  (3 per 64 states)
+//   backward  b' = mismatch' ? fma(b, rho, c1) : b + add_all masked fma, masked add,
+//             sums of b' over all / over mismatching states  accumulate, masked accumulate (4 per 64 states)
+// "masked" = the bit-row word of the site (an SGPR pair fed by s_load_dwordx8, double-buffered one
+// 4-word batch ahead) written into EXEC, so the emission costs no vector instruction.
+//
+// Lanes without a state (the target itself, lanes past N) never mismatch -- the target carries the
+// derived allele at its own sites and pack_rows sets the bits past N -- so their update is "+ rx":
+// before every sweep they are loaded with -rx (VGPR index mode reaches the register of the target's
+// own word) and come out as exact zeros, which keeps every sum and every stone free of masks.
+//
+// gfx950 data hazards are invisible to the compiler inside an asm statement; the statements below
+// carry their own wait states (s_nop) where a vector result feeds v_readlane / DPP / an SGPR read.
+//
+// Internal header; instantiated per G by paint_regs_g*.hip.
+#pragma once
+#include <type_traits>
+
+#include "paint_device.hpp"
+
+namespace relate {
+namespace regs {
+
+using namespace dev;
+
+// ---- register map -------------------------------------------------------------------------------
+#define RELATE_CV 48  // compiler: v0..v47
+#define RELATE_CS 64  // compiler: s0..s63
+// amdgpu_num_sgpr counts the 8 special registers (VCC, FLAT_SCRATCH, XNACK_MASK) on top of s0..s63
+#define RELATE_CS_ATTR 72
+// amdgpu_num_vgpr is doubled by the gfx90a+ back end (unified VGPR/AGPR file); no AGPRs are used here
+#define RELATE_CV_ATTR 24
+constexpr int kCV = RELATE_CV, kCS = RELATE_CS;
+static_assert(RELATE_CS_ATTR == RELATE_CS + 8 && 2 * RELATE_CV_ATTR == RELATE_CV, "register limits");
+constexpr int kX = kCV;       // v[kX:kX+1]   reduction operand
+constexpr int kT = kCV + 2;   // v[kT:kT+1]   scratch pair
+constexpr int kA0 = kCV + 4;  // v[kA0 + 2i : kA0 + 2i + 1] = state of word i
+constexpr int kBufA = kCS, kBufB = kCS + 8, kBufC = kCS + 16, kBufD = kCS + 24;  // 4 x 8 SGPRs of row words
+constexpr int kRL = kBufB;      // readlane results of the reduction (the B buffer is idle then)
+constexpr int kDkN = kCS + 32;  // prefetched list entry
+constexpr int kCnt = kCS + 33;  // loop counter of the padding-lane writes
+constexpr int kCoefN = kCS + 34, kNxN = kCS + 36;  // prefetched per-gap terms (pairs)
+constexpr int kMaxMPL = (256 - kA0) / 2;
+static_assert(kNxN + 1 <= 101, "SGPR map");
+
+#define RELATE_REGS_ATTR __attribute__((amdgpu_num_vgpr(RELATE_CV_ATTR), amdgpu_num_sgpr(RELATE_CS_ATTR)))
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// Tells the compiler which registers the asm statements use by number: it then counts them in the
+// kernel's register budget and keeps its own SGPR-spill lanes out of them (the spill VGPRs are taken
+// from the registers it believes unused, whatever amdgpu_num_vgpr says).  Clobber names must be
+// literals, hence the cumulative lists: RELATE_VCLOB_<MPL> = v48 .. v[kA0 + 2*MPL - 1].
+#define RELATE_VCLOB_4 "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59"
+#define RELATE_VCLOB_8 RELATE_VCLOB_4, "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67"
+#define RELATE_VCLOB_12 RELATE_VCLOB_8, "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75"
+#define RELATE_VCLOB_16 RELATE_VCLOB_12, "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83"
+#define RELATE_VCLOB_20 RELATE_VCLOB_16, "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91"
+#define RELATE_VCLOB_24 RELATE_VCLOB_20, "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99"
+#define RELATE_VCLOB_28 RELATE_VCLOB_24, "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107"
+#define RELATE_VCLOB_32 RELATE_VCLOB_28, "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115"
+#define RELATE_VCLOB_36 RELATE_VCLOB_32, "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123"
+#define RELATE_VCLOB_40 RELATE_VCLOB_36, "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131"
+#define RELATE_VCLOB_48 RELATE_VCLOB_40, "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147"
+#define RELATE_VCLOB_56 RELATE_VCLOB_48, "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163"
+#define RELATE_VCLOB_64 RELATE_VCLOB_56, "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179"
+#define RELATE_VCLOB_72 RELATE_VCLOB_64, "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195"
+#define RELATE_VCLOB_80 RELATE_VCLOB_72, "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211"
+#define RELATE_SCLOB "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101"
+template <int MPL>
+__device__ __forceinline__ void claim_registers();
+#define RELATE_CLAIM(M)                                                \
+  template <>                                                          \
+  __device__ __forceinline__ void claim_registers<M>()                 \
+  {                                                                    \
+    asm volatile("" ::: RELATE_VCLOB_##M, RELATE_SCLOB);               \
+  }
+RELATE_CLAIM(4)
+RELATE_CLAIM(8)
+RELATE_CLAIM(12)
+RELATE_CLAIM(16)
+RELATE_CLAIM(20)
+RELATE_CLAIM(24)
+RELATE_CLAIM(28)
+RELATE_CLAIM(32)
+RELATE_CLAIM(36)
+RELATE_CLAIM(40)
+RELATE_CLAIM(48)
+RELATE_CLAIM(56)
+RELATE_CLAIM(64)
+RELATE_CLAIM(72)
+RELATE_CLAIM(80)
+#undef RELATE_CLAIM
+static_assert(kCV == 48 && kA0 == 52 && kCS == 64, "the clobber lists above are written for this register map");
+
+// A wave-uniform value as an SGPR (the compiler's readfirstlane may be folded into a VGPR copy).
+__device__ __forceinline__ uint32_t sgpr32(uint32_t x)
+{
+  uint32_t r;
+  asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ uint64_t sgpr64(uint64_t x)
+{
+  const uint32_t lo = sgpr32((uint32_t)x), hi = sgpr32((uint32_t)(x >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+// (j == j_edge) ? edge_mask : all ones, on the scalar unit.
+__device__ __forceinline__ uint64_t edge_select(int j, int j_edge, uint64_t edge_mask)
+{
+  uint64_t r;
+  asm volatile("s_cmp_eq_u32 %1, %2\n\ts_cselect_b64 %0, %3, -1" : "=s"(r) : "s"(j), "s"(j_edge), "s"(edge_mask) : "scc");
+  return r;
+}
+
+// ---- row words -------------------------------------------------------------------------------------
+// 4 row words (32 bytes) at p + OFF bytes -> s[SB:SB+7]; asynchronous until swait().
+template <int SB, int OFF>
+__device__ __forceinline__ void sload4(const uint64_t* p)
+{
+  asm volatile("s_load_dwordx8 s[%1:%1+7], %0, %2" ::"s"(p), "n"(SB), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void swait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int DST, int SRC>
+__device__ __forceinline__ void scopy8()
+{
+  asm volatile(
+      "s_mov_b64 s[%0:%0+1], s[%1:%1+1]\n\ts_mov_b64 s[%0+2:%0+3], s[%1+2:%1+3]\n\t"
+      "s_mov_b64 s[%0+4:%0+5], s[%1+4:%1+5]\n\ts_mov_b64 s[%0+6:%0+7], s[%1+6:%1+7]" ::"n"(DST),
+      "n"(SRC));
+}
+// Per-site scalars of the next site, fetched during the sweep of this one.
+__device__ __forceinline__ void prefetch_site(const int32_t* pdk, const double* pcoef, const double* pnx)
+{
+  asm volatile(
+      "s_load_dword s[%3], %0, 0\n\t"
+      "s_load_dwordx2 s[%4:%4+1], %1, 0\n\t"
+      "s_load_dwordx2 s[%5:%5+1], %2, 0" ::"s"(pdk),
+      "s"(pcoef), "s"(pnx), "n"(kDkN), "n"(kCoefN), "n"(kNxN)
+      : "memory");
+}
+__device__ __forceinline__ void fetched_site(int& s, double& coef, double& nx)
+{
+  // s_mov into compiler registers: from here on they are ordinary values
+  uint32_t lo0, hi0, lo1, hi1;
+  asm volatile(
+      "s_mov_b32 %0, s[%5]\n\ts_mov_b32 %1, s[%6]\n\ts_mov_b32 %2, s[%6+1]\n\ts_mov_b32 %3, s[%7]\n\t"
+      "s_mov_b32 %4, s[%7+1]"
+      : "=s"(s), "=s"(lo0), "=s"(hi0), "=s"(lo1), "=s"(hi1)
+      : "n"(kDkN), "n"(kCoefN), "n"(kNxN));
+  coef = __hiloint2double((int)hi0, (int)lo0);
+  nx = __hiloint2double((int)hi1, (int)lo1);
+}
+
+// ---- state block -----------------------------------------------------------------------------------
+template <int I>
+__device__ __forceinline__ void state_set(double v)
+{
+  asm volatile("v_mov_b64 v[%1:%1+1], %0" ::"v"(v), "n"(kA0 + 2 * I));
+}
+template <int I>
+__device__ __forceinline__ void state_scale(double f)
+{
+  asm volatile("v_mul_f64 v[%1:%1+1], v[%1:%1+1], %0" ::"v"(f), "n"(kA0 + 2 * I));
+}
+// float(state I) -> LDS at lds_addr + 256*I (one dword per lane)
+template <int I>
+__device__ __forceinline__ void state_to_lds(uint32_t lds_addr)
+{
+  asm volatile("v_cvt_f32_f64 v[%2], v[%1:%1+1]\n\tds_write_b32 %0, v[%2] offset:%3" ::"v"(lds_addr), "n"(kA0 + 2 * I),
+               "n"(kT + (I & 1)), "n"(256 * I)
+               : "memory");
+}
+
+// Lanes without a state <- v: the target's own lane (selfm = its bit, or 0 if its word belongs to
+// another wave; selfidx = 2 * local word) and every lane from the first padding lane of the wave on
+// (phm = lanes of that word, phidx = 2 * its local word; 2*MPL if the wave has none).
+template <int MPL>
+__device__ __forceinline__ void write_stateless(double v, uint64_t selfm, uint32_t selfidx, uint64_t phm, uint32_t phidx)
+{
+  asm volatile(
+      "v_mov_b64 v[%[t]:%[t]+1], %[v]\n\t"
+      "s_mov_b64 exec, %[selfm]\n\t"
+      "s_set_gpr_idx_on %[selfidx], 8\n\t"
+      "s_nop 1\n\t"
+      "v_mov_b32 v[%[a0]], v[%[t]]\n\t"
+      "v_mov_b32 v[%[a0]+1], v[%[t]+1]\n\t"
+      "s_set_gpr_idx_off\n\t"
+      "s_mov_b32 s[%[cnt]], %[phidx]\n\t"
+      "s_mov_b64 exec, %[phm]\n\t"
+      "s_cmp_ge_u32 s[%[cnt]], %[end]\n\t"
+      "s_cbranch_scc1 .Lws_done%=\n"
+      ".Lws_loop%=:\n\t"
+      "s_set_gpr_idx_on s[%[cnt]], 8\n\t"
+      "s_nop 1\n\t"
+      "v_mov_b32 v[%[a0]], v[%[t]]\n\t"
+      "v_mov_b32 v[%[a0]+1], v[%[t]+1]\n\t"
+      "s_set_gpr_idx_off\n\t"
+      "s_mov_b64 exec, -1\n\t"
+      "s_add_u32 s[%[cnt]], s[%[cnt]], 2\n\t"
+      "s_cmp_lt_u32 s[%[cnt]], %[end]\n\t"
+      "s_cbranch_scc1 .Lws_loop%=\n"
+      ".Lws_done%=:\n\t"
+      "s_mov_b64 exec, -1"
+      :
+      : [v] "v"(v), [selfm] "s"(selfm), [selfidx] "s"(selfidx), [phm] "s"(phm), [phidx] "s"(phidx), [t] "n"(kT),
+        [a0] "n"(kA0), [cnt] "n"(kCnt), [end] "n"(2 * MPL)
+      : "scc", "memory");
+}
+
+// ---- sweeps ----------------------------------------------------------------------------------------
+#define RELATE_A(i) "v[%[r]+" #i "*2:%[r]+" #i "*2+1]"
+#define RELATE_W(sb, i) "s[%[" #sb "]+" #i "*2:%[" #sb "]+" #i "*2+1]"
+
+#define RELATE_FWD_ADD(i) "v_add_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[rx]\n\t"
+#define RELATE_FWD_MUL(i) "s_andn2_b64 exec, %[sk], " RELATE_W(s, i) "\n\tv_mul_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[rho]\n\t"
+#define RELATE_FWD_ACC(i) "v_add_f64 %[c" #i "], %[c" #i "], " RELATE_A(i) "\n\t"
+
+// forward sweep over NW (1..4) words: states kA0+2*W0.., row words in s[SB..]
+template <int W0, int SB, int NW>
+__device__ __forceinline__ void fwd_batch(double& c0, double& c1, double& c2, double& c3, double rx, double rho, uint64_t sk)
+{
+#define RELATE_FWD_OPS                                                                                         \
+  : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3)                                                 \
+  : [rx] "v"(rx), [rho] "v"(rho), [sk] "s"(sk), [r] "n"(kA0 + 2 * W0), [s] "n"(SB)                             \
+  : "scc"
+  if constexpr (NW == 4)
+    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2) RELATE_FWD_ADD(3)
+                 RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2) RELATE_FWD_MUL(3)
+                 "s_mov_b64 exec, -1\n\t"
+                 RELATE_FWD_ACC(0) RELATE_FWD_ACC(1) RELATE_FWD_ACC(2) RELATE_FWD_ACC(3) RELATE_FWD_OPS);
+  else if constexpr (NW == 3)
+    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2)
+                 RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2)
+                 "s_mov_b64 exec, -1\n\t"
+                 RELATE_FWD_ACC(0) RELATE_FWD_ACC(1) RELATE_FWD_ACC(2) RELATE_FWD_OPS);
+  else if constexpr (NW == 2)
+    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_MUL(0) RELATE_FWD_MUL(1)
+                 "s_mov_b64 exec, -1\n\t"
+                 RELATE_FWD_ACC(0) RELATE_FWD_ACC(1) RELATE_FWD_OPS);
+  else
+    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_MUL(0) "s_mov_b64 exec, -1\n\t" RELATE_FWD_ACC(0) RELATE_FWD_OPS);
+#undef RELATE_FWD_OPS
+}
+
+#define RELATE_BWD_FMA(i) \
+  "s_andn2_b64 exec, %[skn], " RELATE_W(sn, i) "\n\tv_fma_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[rho], %[c1]\n\t"
+#define RELATE_BWD_ADD(i) \
+  "s_orn2_b64 exec, " RELATE_W(sn, i) ", %[skn]\n\tv_add_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[aa]\n\t"
+#define RELATE_BWD_ALL(i) "v_add_f64 %[ca" #i "], %[ca" #i "], " RELATE_A(i) "\n\t"
+#define RELATE_BWD_MIS(i) \
+  "s_andn2_b64 exec, %[skc], " RELATE_W(sc, i) "\n\tv_add_f64 %[cm" #i "], %[cm" #i "], " RELATE_A(i) "\n\t"
+
+struct BwdAcc {
+  double a0, a1, a2, a3;  // sums over all states
+  double m0, m1, m2, m3;  // sums over the states that mismatch at the current site
+};
+
+// backward sweep over NW words: update with the masks of the row handled one step earlier (s[SN..],
+// skn), sums with the masks of the current row (s[SC..], skc)
+template <int W0, int SN, int SC, int NW>
+__device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, double aa, uint64_t skn, uint64_t skc)
+{
+#define RELATE_BWD_OPS                                                                                         \
+  : [ca0] "+v"(c.a0), [ca1] "+v"(c.a1), [ca2] "+v"(c.a2), [ca3] "+v"(c.a3), [cm0] "+v"(c.m0), [cm1] "+v"(c.m1), \
+    [cm2] "+v"(c.m2), [cm3] "+v"(c.m3)                                                                         \
+  : [rho] "v"(rho), [c1] "v"(c1), [aa] "v"(aa), [skn] "s"(skn), [skc] "s"(skc), [r] "n"(kA0 + 2 * W0),        \
+    [sn] "n"(SN), [sc] "n"(SC)                                                                                 \
+  : "scc"
+  if constexpr (NW == 4)
+    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3)
+                 RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2) RELATE_BWD_ADD(3)
+                 "s_mov_b64 exec, -1\n\t"
+                 RELATE_BWD_ALL(0) RELATE_BWD_ALL(1) RELATE_BWD_ALL(2) RELATE_BWD_ALL(3)
+                 RELATE_BWD_MIS(0) RELATE_BWD_MIS(1) RELATE_BWD_MIS(2) RELATE_BWD_MIS(3)
+                 "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
+  else if constexpr (NW == 3)
+    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2)
+                 RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2)
+                 "s_mov_b64 exec, -1\n\t"
+                 RELATE_BWD_ALL(0) RELATE_BWD_ALL(1) RELATE_BWD_ALL(2)
+                 RELATE_BWD_MIS(0) RELATE_BWD_MIS(1) RELATE_BWD_MIS(2)
+                 "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
+  else if constexpr (NW == 2)
+    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_ADD(0) RELATE_BWD_ADD(1)
+                 "s_mov_b64 exec, -1\n\t"
+                 RELATE_BWD_ALL(0) RELATE_BWD_ALL(1) RELATE_BWD_MIS(0) RELATE_BWD_MIS(1)
+                 "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
+  else
+    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_ADD(0) "s_mov_b64 exec, -1\n\t" RELATE_BWD_ALL(0) RELATE_BWD_MIS(0)
+                 "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
+#undef RELATE_BWD_OPS
+}
+
+// ---- reductions ------------------------------------------------------------------------------------
+#define RELATE_DPP_STEP(ctrl)                                                            \
+  "s_nop 1\n\t"                                                                          \
+  "v_mov_b32_dpp v[%[t]], v[%[x]] " ctrl " row_mask:0xf bank_mask:0xf\n\t"               \
+  "v_mov_b32_dpp v[%[t]+1], v[%[x]+1] " ctrl " row_mask:0xf bank_mask:0xf\n\t"           \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"
+
+// Sum over the 64 lanes, the same bits in every lane: four exchange steps inside each 16-lane row,
+// then the four row sums through SGPRs, added as (r0 + r1) + (r2 + r3).
+__device__ __forceinline__ double wave_sum_regs(double x)
+{
+  double out;
+  asm volatile(
+      "v_mov_b64 v[%[x]:%[x]+1], %[in]\n\t"
+      RELATE_DPP_STEP("quad_perm:[1,0,3,2]")
+      RELATE_DPP_STEP("quad_perm:[2,3,0,1]")
+      RELATE_DPP_STEP("row_half_mirror")
+      RELATE_DPP_STEP("row_mirror")
+      "s_nop 0\n\t"
+      "v_readlane_b32 s[%[rl]+0], v[%[x]], 0\n\t"
+      "v_readlane_b32 s[%[rl]+1], v[%[x]+1], 0\n\t"
+      "v_readlane_b32 s[%[rl]+2], v[%[x]], 16\n\t"
+      "v_readlane_b32 s[%[rl]+3], v[%[x]+1], 16\n\t"
+      "v_readlane_b32 s[%[rl]+4], v[%[x]], 32\n\t"
+      "v_readlane_b32 s[%[rl]+5], v[%[x]+1], 32\n\t"
+      "v_readlane_b32 s[%[rl]+6], v[%[x]], 48\n\t"
+      "v_readlane_b32 s[%[rl]+7], v[%[x]+1], 48\n\t"
+      "s_nop 1\n\t"
+      "v_mov_b64 v[%[t]:%[t]+1], s[%[rl]+2:%[rl]+3]\n\t"
+      "v_add_f64 v[%[t]:%[t]+1], s[%[rl]:%[rl]+1], v[%[t]:%[t]+1]\n\t"
+      "v_mov_b64 v[%[x]:%[x]+1], s[%[rl]+6:%[rl]+7]\n\t"
+      "v_add_f64 v[%[x]:%[x]+1], s[%[rl]+4:%[rl]+5], v[%[x]:%[x]+1]\n\t"
+      "v_add_f64 %[out], v[%[t]:%[t]+1], v[%[x]:%[x]+1]"
+      : [out] "=v"(out)
+      : [in] "v"(x), [x] "n"(kX), [t] "n"(kT), [rl] "n"(kRL));
+  return out;
+}
+
+// Sum over the G waves of the workgroup; `slot` alternates between two LDS rows so that one barrier
+// per call is enough (a row is rewritten two calls later, after every wave has passed the barrier of
+// the call in between).
+template <int G>
+__device__ __forceinline__ double block_sum_regs(double x, double (*red)[G], int& slot)
+{
+  x = wave_sum_regs(x);
+  if constexpr (G == 1) {
+    return x;
+  } else {
+    const int wv = threadIdx.x >> 6;
+    if (lane_id() == 0) red[slot][wv] = x;
+    __syncthreads();
+    double s = red[slot][0];
+#pragma unroll
+    for (int g = 1; g < G; g++) s += red[slot][g];
+    slot ^= 1;
+    return s;
+  }
+}
+
+// ---- kernel ----------------------------------------------------------------------------------------
+template <int MPL, int G>
+__global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(
+    const uint64_t* __restrict__ rows, const int32_t* __restrict__ dk_all, const double* __restrict__ coef_all,
+    const double* __restrict__ nx_all, const int64_t* __restrict__ off, const int32_t* __restrict__ nd_all,
+    const int32_t* __restrict__ bbj_all, const int32_t* __restrict__ bej_all, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ wb, uint8_t* __restrict__ out, const Scal p)
+{
+  static_assert(MPL >= 1 && MPL <= kMaxMPL, "states per lane");
+  constexpr int NB = (MPL + 3) / 4;  // 4-word batches per wave and site
+  constexpr int LASTW = MPL - 4 * (NB - 1);
+  // Dynamic LDS (sized by the launcher): with a static allocation the compiler derives an occupancy
+  // bound from it and then ignores amdgpu_num_sgpr.  Two rows of G partial sums, then the staging
+  // buffer of one stone payload (G * MPL * 64 floats).
+  extern __shared__ double lds_dyn[];
+  double (*red)[G] = reinterpret_cast<double (*)[G]>(lds_dyn);
+  float* stage = reinterpret_cast<float*>(lds_dyn + 2 * G);
+  claim_registers<MPL>();
+  int slot = 0;
+  const int t = __builtin_amdgcn_readfirstlane(order[blockIdx.x]);
+  const int k = p.k_begin + t;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wbase = wave * MPL;
+  const int N = p.N, W = p.W, stride = p.row_stride, L = p.L, K = p.K;
+  const int nd = __builtin_amdgcn_readfirstlane(nd_all[t]);
+  const long long o = off[t];
+  const int32_t* __restrict__ dk = dk_all + o;
+  const double* __restrict__ coef = coef_all + o;
+  const double* __restrict__ nx = nx_all + o;
+  const int32_t* __restrict__ bbj = bbj_all + (long long)t * W;
+  const int32_t* __restrict__ bej = bej_all + (long long)t * W;
+  const size_t R = 56 + (size_t)8 * N;
+  const int kw = k >> 6, kb = k & 63;
+  const bool first_thread = threadIdx.x == 0;
+  const int full_words = N >> 6, rem = N & 63;
+  const uint64_t* rows_w = rows + wbase;  // the words of this wave start here in every row
+
+  // lanes without a state
+  const bool self_here = kw >= wbase && kw < wbase + MPL;
+  const uint64_t selfm = sgpr64(self_here ? (1ull << kb) : 0ull);
+  const uint32_t selfidx = sgpr32(self_here ? 2u * (uint32_t)(kw - wbase) : 0u);
+  const int w_ph = full_words > wbase ? full_words : wbase;  // first word of this wave with padding lanes
+  const uint64_t phm = sgpr64((w_ph == full_words && rem) ? ~((1ull << rem) - 1ull) : ~0ull);
+  const uint32_t phidx = sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL);
+
+  // bit of the target itself at the two forced sites; it is '1' at every other site of its list
+  const uint64_t sk_first = sgpr64(((rows[kw] >> kb) & 1ull) ? ~0ull : 0ull);
+  const uint64_t sk_last = sgpr64(((rows[(size_t)(L - 1) * stride + kw] >> kb) & 1ull) ? ~0ull : 0ull);
+
+  const uint32_t lds_mine = (uint32_t)(uintptr_t)(stage + wbase * 64 + lane);
+
+  // Stone payload (src/fast_painting.cpp:368-388,:573-592): every lane drops its states as floats into
+  // LDS, then the workgroup streams the N floats out with coalesced stores; the target's own entry is
+  // an exact zero already (:312,:507).
+  auto store_states = [&](float* __restrict__ dst) __attribute__((always_inline)) {
+    const uint32_t a = lds_mine;
+    static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) { state_to_lds<decltype(ic)::value>(a); });
+    swait();
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 64 * G) dst[n] = stage[n];
+    __syncthreads();
+  };
+
+  // ---------------- forward (src/fast_painting.cpp:214-408) ----------------
+  {
+    double acc = 0.0;
+    const double prior_mis = p.c.prior_mis, prior_match = p.c.prior_match;
+    static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      const int wi = wbase + i;
+      const uint64_t w = rows_w[i];
+      const bool v = __builtin_amdgcn_inverse_ballot_w64(valid_mask(wi, N, k));
+      const bool m = __builtin_amdgcn_inverse_ballot_w64(~w & sk_first);
+      const double a = m ? prior_mis : prior_match;
+      state_set<i>(v ? a : 0.0);
+      acc += v ? a : 0.0;
+    });
+    double S = block_sum_regs<G>(acc, red, slot);
+    double ls = 0.0;
+    int wcur = 0;
+    int stone_j = 0;  // list index at which the next alpha stone is due (window 0 starts at site 0)
+    auto emit = [&](int j, int s) __attribute__((always_inline)) {
+      while (stone_j == j) {
+        uint8_t* rec = out + ((size_t)wcur * K + t) * R;
+        if (first_thread) {
+          put_u32(rec, (uint32_t)wb[wcur]);
+          put_u32(rec + 4, (uint32_t)(wb[wcur + 1] - 1));
+          put_block_header(rec + 8, N, s, (float)ls);
+        }
+        store_states(reinterpret_cast<float*>(rec + 32));
+        wcur++;
+        stone_j = wcur < W ? __builtin_amdgcn_readfirstlane(bbj[wcur]) : -1;
+      }
+    };
+    emit(0, 0);
+    const double rho = p.c.rho_theta, lo = p.c.lo, hi = p.c.hi;
+    int s_cur = __builtin_amdgcn_readfirstlane(dk[1]);  // nd >= 2: sites 0 and L-1 are always listed
+    int s_next = __builtin_amdgcn_readfirstlane(dk[2 < nd ? 2 : nd - 1]);
+    double coef_j = coef[0], nx_j = nx[0];  // terms of the gap before site j
+    const uint64_t* rp = rows_w + (size_t)s_cur * stride;
+    sload4<kBufA, 0>(rp);
+    swait();
+    for (int j = 1; j < nd; j++) {
+      const double rx = S * coef_j;
+      write_stateless<MPL>(-rx, selfm, selfidx, phm, phidx);
+      // scalars of site j+1 travel during this sweep: its successor in the list and the terms of the gap before it
+      prefetch_site(dk + (j + 2 < nd ? j + 2 : nd - 1), coef + j, nx + j);
+      const uint64_t skm = edge_select(j, nd - 1, sk_last);
+      ls += nx_j;
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+      const uint64_t* rp_next = rows_w + (size_t)s_next * stride;
+      static_for<0, NB>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int b = decltype(ic)::value;
+        constexpr int cur = (b & 1) ? kBufB : kBufA;
+        constexpr int nxt = (b & 1) ? kBufA : kBufB;
+        const uint64_t* rpl = rp;
+        const uint64_t* rpn = rp_next;
+        if constexpr (b + 1 < NB) sload4<nxt, (b + 1) * 32>(rpl);
+        else sload4<nxt, 0>(rpn);
+        const double rxl = rx, rhol = rho;
+        const uint64_t skl = skm;
+        fwd_batch<4 * b, cur, (b + 1 < NB ? 4 : LASTW)>(c0, c1, c2, c3, rxl, rhol, skl);
+        swait();
+      });
+      if constexpr (NB & 1) scopy8<kBufA, kBufB>();
+      S = block_sum_regs<G>((c0 + c1) + (c2 + c3), red, slot);
+      int s_next2;
+      fetched_site(s_next2, coef_j, nx_j);
+      if (S < lo || S > hi) {
+        const double inv = 1.0 / S;
+        static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
+          const double f = inv;
+          state_scale<decltype(ic)::value>(f);
+        });
+        ls += log(S);
+        S = 1.0;
+      }
+      emit(j, s_cur);
+      s_cur = s_next;
+      s_next = s_next2;
+      rp = rp_next;
+    }
+  }
+
+  // ---------------- backward (src/fast_painting.cpp:410-599) ----------------
+  {
+    const double theta_d = p.c.theta_d, ntheta_d = p.c.ntheta_d;
+    double ls = p.c.log_Nm1 - (double)nd * p.c.log_ntheta;
+    const uint64_t* row_last = rows_w + (size_t)(L - 1) * stride;
+    double acc = 0.0;
+    static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      const int wi = wbase + i;
+      const uint64_t w = row_last[i];
+      const bool v = __builtin_amdgcn_inverse_ballot_w64(valid_mask(wi, N, k));
+      const bool m = __builtin_amdgcn_inverse_ballot_w64(~w & sk_last);
+      state_set<i>(1.0);
+      acc += v ? (m ? theta_d : ntheta_d) : 0.0;
+    });
+    double B = block_sum_regs<G>(acc, red, slot);
+    int wcur = W - 1;
+    int stone_j = __builtin_amdgcn_readfirstlane(bej[W - 1]);  // == nd-1: the last window ends at the last SNP
+    // stones taken at the last SNP hold beta = 1 for every state, the target included (:427-432,:447-462)
+    while (stone_j == nd - 1) {
+      uint8_t* rec = out + ((size_t)wcur * K + t) * R;
+      if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, L - 1, (float)ls);
+      float* dst = reinterpret_cast<float*>(rec + 56 + (size_t)4 * N);
+      for (int n = threadIdx.x; n < N; n += 64 * G) dst[n] = 1.0f;
+      wcur--;
+      stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(bej[wcur]) : -1;
+    }
+    const double rho = p.c.rho_theta, lo = p.c.lo, hi = p.c.hi;
+    const double inv_nt = p.c.inv_ntheta_d, inv_t = p.c.inv_theta_d;
+    const double w_all = ntheta_d, w_mis = theta_d - ntheta_d;
+    int s_cur = __builtin_amdgcn_readfirstlane(dk[nd - 2]);
+    int s_prev = __builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]);
+    double coef_j = coef[nd - 1], nx_j = nx[nd - 1];  // terms used by the step to site j: index j + 1
+    const uint64_t* rp_n = row_last;
+    const uint64_t* rp_c = rows_w + (size_t)s_cur * stride;
+    sload4<kBufA, 0>(rp_n);
+    sload4<kBufC, 0>(rp_c);
+    swait();
+    for (int j = nd - 2; j >= 0; j--) {
+      // beta' = (beta + mis'*b + a) * (mis' ? rho : 1), a = rx/(1-theta), b = rx/theta - a (:488-502), as
+      // matching states: beta + a; mismatching states: fma(beta, rho, (b + a)*rho)
+      const double rx = B * coef_j;
+      const double aa = rx * inv_nt;
+      const double bb = rx * inv_t - aa;
+      const double c1 = (bb + aa) * rho;
+      write_stateless<MPL>(-aa, selfm, selfidx, phm, phidx);
+      // scalars of the step to site j-1 travel during this sweep
+      prefetch_site(dk + (j > 1 ? j - 2 : 0), coef + j, nx + j);
+      const uint64_t skn = edge_select(j, nd - 2, sk_last);
+      const uint64_t skc = edge_select(j, 0, sk_first);
+      ls += nx_j;
+      BwdAcc c = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      const uint64_t* rp_p = rows_w + (size_t)s_prev * stride;
+      static_for<0, NB>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int b = decltype(ic)::value;
+        constexpr int curn = (b & 1) ? kBufB : kBufA;
+        constexpr int nxtn = (b & 1) ? kBufA : kBufB;
+        constexpr int curc = (b & 1) ? kBufD : kBufC;
+        constexpr int nxtc = (b & 1) ? kBufC : kBufD;
+        const uint64_t* pn = rp_n;
+        const uint64_t* pc = rp_c;
+        const uint64_t* pq = rp_p;
+        if constexpr (b + 1 < NB) {
+          sload4<nxtn, (b + 1) * 32>(pn);
+          sload4<nxtc, (b + 1) * 32>(pc);
+        } else {
+          sload4<nxtn, 0>(pc);
+          sload4<nxtc, 0>(pq);
+        }
+        const double rhol = rho, c1l = c1, aal = aa;
+        const uint64_t sknl = skn, skcl = skc;
+        bwd_batch<4 * b, curn, curc, (b + 1 < NB ? 4 : LASTW)>(c, rhol, c1l, aal, sknl, skcl);
+        swait();
+      });
+      if constexpr (NB & 1) {
+        scopy8<kBufA, kBufB>();
+        scopy8<kBufC, kBufD>();
+      }
+      // B = (1-theta) * sum over matching states + theta * sum over mismatching states (:509-517)
+      B = block_sum_regs<G>(w_all * ((c.a0 + c.a1) + (c.a2 + c.a3)) + w_mis * ((c.m0 + c.m1) + (c.m2 + c.m3)), red, slot);
+      int s_prev2;
+      fetched_site(s_prev2, coef_j, nx_j);
+      if (B < lo || B > hi) {
+        const double inv = 1.0 / B;
+        static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
+          const double f = inv;
+          state_scale<decltype(ic)::value>(f);
+        });
+        ls += (double)fast_log_dev((float)B);  // float approximation on this side (:562)
+        B = 1.0;
+      }
+      while (stone_j == j) {
+        uint8_t* rec = out + ((size_t)wcur * K + t) * R;
+        if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, s_cur, (float)ls);
+        store_states(reinterpret_cast<float*>(rec + 56 + (size_t)4 * N));
+        wcur--;
+        stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(bej[wcur]) : -1;
+      }
+      s_cur = s_prev;
+      s_prev = s_prev2;
+      rp_n = rp_c;
+      rp_c = rp_p;
+    }
+  }
+}
+
+template <int MPL, int G>
+inline hipError_t launch_regs_t(const PaintArgs& a, hipStream_t st)
+{
+  // the stone staging buffer must fit in the 160 KiB of LDS of a CU
+  constexpr size_t lds_bytes = (size_t)G * MPL * 256 + 2 * G * 8;
+  if constexpr (lds_bytes > 160 * 1024) {
+    return hipErrorInvalidValue;
+  } else {
+    if (lds_bytes > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&paint_kernel_r<MPL, G>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      if (e != hipSuccess) return e;
+    }
+    Scal s;
+    s.row_stride = a.row_stride;
+    s.N = a.N;
+    s.L = a.L;
+    s.W = a.W;
+    s.k_begin = a.k_begin;
+    s.K = a.K;
+    s.c = a.c;
+    hipLaunchKernelGGL((paint_kernel_r<MPL, G>), dim3(a.K), dim3(64 * G), lds_bytes, st, a.rows, a.dk, a.coef, a.nx,
+                       a.off, a.nd, a.bbj, a.bej, a.order, a.wb, a.out, s);
+    return hipGetLastError();
+  }
+}
+
+// Dispatch on MPL for one G.
+template <int G>
+inline hipError_t launch_regs_g(const PaintArgs& a, int MPL, hipStream_t st)
+{
+  switch (MPL) {
+#define RELATE_CASE(M) \
+  case M: return launch_regs_t<M, G>(a, st);
+    RELATE_CASE(4) RELATE_CASE(8) RELATE_CASE(12) RELATE_CASE(16) RELATE_CASE(20) RELATE_CASE(24) RELATE_CASE(28)
+    RELATE_CASE(32) RELATE_CASE(36) RELATE_CASE(40) RELATE_CASE(48) RELATE_CASE(56) RELATE_CASE(64) RELATE_CASE(72)
+    RELATE_CASE(80)
+#undef RELATE_CASE
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace regs
+}  // namespace relate

@@ -1,0 +1,6 @@
+// Instantiates the register-resident recursion kernel for 4 wave(s) per target.
+#include "paint_regs.hpp"
+
+namespace relate {
+hipError_t launch_paint_regs_g4(const PaintArgs& a, int MPL, hipStream_t st) { return regs::launch_regs_g<4>(a, MPL, st); }
+}  // namespace relate

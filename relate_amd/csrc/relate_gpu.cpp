@@ -91,6 +91,8 @@ relate::PaintConsts make_consts(int N, double theta_p, double theta_d)
   c.log_Nm1 = std::log(c.Nm1);
   c.theta_d = theta_d;
   c.ntheta_d = 1.0 - theta_d;
+  c.inv_theta_d = 1.0 / c.theta_d;
+  c.inv_ntheta_d = 1.0 / c.ntheta_d;
   c.lo = 1e-10;
   c.hi = 1.0 / c.lo;
   return c;
@@ -213,7 +215,7 @@ void relate_plan_destroy(relate_plan* p)
 int relate_plan_configure(relate_plan* p, int variant, int waves_per_target)
 {
   if (!p) return fail(RELATE_EINVAL, "null plan");
-  if (variant != 0 && variant != 1) return fail(RELATE_EINVAL, "variant must be 0 or 1");
+  if (variant < 0 || variant > 2) return fail(RELATE_EINVAL, "variant must be 0, 1 or 2");
   if (waves_per_target != 0 && waves_per_target != 1 && waves_per_target != 2 && waves_per_target != 4 &&
       waves_per_target != 8)
     return fail(RELATE_EINVAL, "waves_per_target must be 0, 1, 2, 4 or 8");

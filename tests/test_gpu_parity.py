@@ -83,12 +83,14 @@ def test_fast_log_bit_exact():
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
-@pytest.mark.parametrize("variant,waves", [(1, 0), (1, 2), (1, 4), (0, 0), (0, 2)])
+@pytest.mark.parametrize("variant,waves", [(2, 0), (2, 2), (2, 4), (2, 8), (1, 0), (1, 2), (1, 4), (0, 0), (0, 2)])
 def test_golden_vectors(name, variant, waves):
     g = load_golden(name)
     got = gpu_paint(g["seq"], g["r"], g["theta_painter"], g["theta_data"], g["wb"], variant, waves)
     frac = compare_records(got, g["stones"], g["N"], f"{name} v{variant} g{waves}")
-    assert frac < 1e-3, f"{frac:.2e} of the floats are not bit-identical to the reference"
+    # variants 0 and 1 round every operation as the reference does and differ only in the order of the
+    # sums; variant 2 also fuses / reassociates the backward update, so more last bits differ
+    assert frac < (1e-3 if variant < 2 else 0.2), f"{frac:.2e} of the floats are not bit-identical to the reference"
 
 
 def test_entry_point_host_buffers_matches_golden():
@@ -110,12 +112,13 @@ def test_entry_point_host_buffers_matches_golden():
     (2048, 600, 2, 26, "flat", 0.001, 0.001, 0),     # N a multiple of 64: no partial word
     (2, 50, 2, 27, "flat", 0.01, 0.01, 0),           # smallest N
 ])
-def test_against_oracle(N, L, W, seed, mode, tp, td, waves):
+@pytest.mark.parametrize("variant", [2, 1])
+def test_against_oracle(N, L, W, seed, mode, tp, td, waves, variant):
     seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=seed, r_mode=mode, empty_window=(W >= 3))
     want = ol.oracle().paint_stones(seq, r, tp, td, wb)
-    got = gpu_paint(seq, r, tp, td, wb, 1, waves)
-    frac = compare_records(got, want, N, f"N={N} L={L}")
-    assert frac < 1e-3
+    got = gpu_paint(seq, r, tp, td, wb, variant, waves)
+    frac = compare_records(got, want, N, f"N={N} L={L} v{variant}")
+    assert frac < (1e-3 if variant < 2 else 0.2)
 
 
 def test_full_size_sampled_targets_and_structure():

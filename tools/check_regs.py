@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Build-time check of the register-resident recursion kernels (relate_amd/csrc/paint_regs.hpp).
+
+The kernels keep their state in VGPRs >= 48 and their row buffers in SGPRs >= 64, addressed by number
+from inline asm, and rely on the compiler staying below those limits.  This script reads the device
+assembly (hipcc -S --cuda-device-only) of the instantiation files and fails if any instruction the
+COMPILER emitted (i.e. outside the asm statements) inside a paint_kernel_r kernel names v48+ or s64+.
+
+    python tools/check_regs.py relate_amd/csrc/paint_regs_g1.s ...
+"""
+import re
+import sys
+
+V_LIMIT, S_LIMIT = 48, 64
+REG = re.compile(r"\b([vs])(\d+)\b|\b([vs])\[(\d+):(\d+)\]")
+
+
+def check(path):
+    bad = []
+    kernel = None
+    in_asm = False
+    counts = {}
+    for ln, line in enumerate(open(path), 1):
+        m = re.match(r"^(_ZN6relate4regs14paint_kernel_r\w+):", line)
+        if m:
+            kernel = m.group(1)
+            counts[kernel] = 0
+            continue
+        if line.startswith("\t.end_amdhsa_kernel") or ".Lfunc_end" in line:
+            kernel = None
+        if kernel is None:
+            continue
+        if "#ASMSTART" in line:
+            in_asm = True
+            continue
+        if "#ASMEND" in line:
+            in_asm = False
+            continue
+        code = line.split(";")[0]
+        if in_asm or not code.strip() or code.lstrip().startswith("."):
+            continue
+        counts[kernel] += 1
+        for r in REG.finditer(code):
+            if r.group(1):
+                cls, hi = r.group(1), int(r.group(2))
+            else:
+                cls, hi = r.group(3), int(r.group(5))
+            if hi >= (V_LIMIT if cls == "v" else S_LIMIT):
+                bad.append(f"{path}:{ln}: {kernel[:60]}: {code.strip()}")
+    return counts, bad
+
+
+def main():
+    total_bad = []
+    nk = 0
+    for p in sys.argv[1:]:
+        counts, bad = check(p)
+        nk += len(counts)
+        total_bad += bad
+    if nk == 0:
+        print("check_regs: no paint_kernel_r kernels found", file=sys.stderr)
+        return 2
+    if total_bad:
+        print("\n".join(total_bad[:40]), file=sys.stderr)
+        print(f"check_regs: {len(total_bad)} compiler instructions touch reserved registers", file=sys.stderr)
+        return 1
+    print(f"check_regs: {nk} kernels clean")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
