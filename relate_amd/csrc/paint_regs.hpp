@@ -367,12 +367,34 @@ __device__ __forceinline__ double block_sum_regs(double x, double (*red)[G], int
 }
 
 // ---- kernel ----------------------------------------------------------------------------------------
+// Kernel arguments as one struct, so that the rarely used ones can be fetched from the kernel-argument
+// segment where they are needed instead of occupying scalar registers across the sweeps.
+struct KArgs {
+  const uint64_t* rows;
+  const int32_t* dk_all;
+  const double* coef_all;
+  const double* nx_all;
+  const int64_t* off;
+  const int32_t* nd_all;
+  const int32_t* bbj_all;
+  const int32_t* bej_all;
+  const int32_t* order;
+  const int32_t* wb;
+  uint8_t* out;
+  Scal p;
+};
+typedef const __attribute__((address_space(4))) KArgs* KArgsPtr;
+// The argument segment again, as a pointer the optimiser knows nothing about: loads through it stay
+// where they are written (inside the stone / rescale paths) and are not hoisted above the loops.
+__device__ __forceinline__ KArgsPtr rare_args()
+{
+  KArgsPtr q = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  return q;
+}
+
 template <int MPL, int G>
-__global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(
-    const uint64_t* __restrict__ rows, const int32_t* __restrict__ dk_all, const double* __restrict__ coef_all,
-    const double* __restrict__ nx_all, const int64_t* __restrict__ off, const int32_t* __restrict__ nd_all,
-    const int32_t* __restrict__ bbj_all, const int32_t* __restrict__ bej_all, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ wb, uint8_t* __restrict__ out, const Scal p)
+__global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const KArgs ka)
 {
   static_assert(MPL >= 1 && MPL <= kMaxMPL, "states per lane");
   constexpr int NB = (MPL + 3) / 4;  // 4-word batches per wave and site
@@ -385,43 +407,55 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(
   float* stage = reinterpret_cast<float*>(lds_dyn + 2 * G);
   claim_registers<MPL>();
   int slot = 0;
-  const int t = __builtin_amdgcn_readfirstlane(order[blockIdx.x]);
-  const int k = p.k_begin + t;
+  // The two passes of a target are independent until their stones meet in the record, so they run as
+  // two workgroups: twice as many waves to interleave on a SIMD, with nothing to exchange.  Which of
+  // the pair 2i, 2i+1 takes which pass follows the parity of the set bits of the block index, so that
+  // every power-of-two stride of the dispatcher (XCDs, CUs, SIMDs) sees both kinds.
+  const int pass = __builtin_popcount(blockIdx.x) & 1;
+  const int t = __builtin_amdgcn_readfirstlane(ka.order[blockIdx.x >> 1]);
+  const int k = ka.p.k_begin + t;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wbase = wave * MPL;
-  const int N = p.N, W = p.W, stride = p.row_stride, L = p.L, K = p.K;
-  const int nd = __builtin_amdgcn_readfirstlane(nd_all[t]);
-  const long long o = off[t];
-  const int32_t* __restrict__ dk = dk_all + o;
-  const double* __restrict__ coef = coef_all + o;
-  const double* __restrict__ nx = nx_all + o;
-  const int32_t* __restrict__ bbj = bbj_all + (long long)t * W;
-  const int32_t* __restrict__ bej = bej_all + (long long)t * W;
-  const size_t R = 56 + (size_t)8 * N;
+  const int stride = ka.p.row_stride;
+  const int nd = __builtin_amdgcn_readfirstlane(ka.nd_all[t]);
+  const long long o = ka.off[t];
+  const int32_t* __restrict__ dk = ka.dk_all + o;
+  const double* __restrict__ coef = ka.coef_all + o;
+  const double* __restrict__ nx = ka.nx_all + o;
   const int kw = k >> 6, kb = k & 63;
   const bool first_thread = threadIdx.x == 0;
-  const int full_words = N >> 6, rem = N & 63;
-  const uint64_t* rows_w = rows + wbase;  // the words of this wave start here in every row
+  const uint64_t* rows_w = ka.rows + wbase;  // the words of this wave start here in every row
 
-  // lanes without a state
-  const bool self_here = kw >= wbase && kw < wbase + MPL;
-  const uint64_t selfm = sgpr64(self_here ? (1ull << kb) : 0ull);
-  const uint32_t selfidx = sgpr32(self_here ? 2u * (uint32_t)(kw - wbase) : 0u);
-  const int w_ph = full_words > wbase ? full_words : wbase;  // first word of this wave with padding lanes
-  const uint64_t phm = sgpr64((w_ph == full_words && rem) ? ~((1ull << rem) - 1ull) : ~0ull);
-  const uint32_t phidx = sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL);
+  // Lanes without a state: the target's own (selfm = its bit, or 0 if its word belongs to another wave)
+  // and the padding lanes from the first incomplete word of this wave on.
+  struct Stateless {
+    uint64_t selfm, phm;
+    uint32_t selfidx, phidx;
+  };
+  auto stateless = [&]() __attribute__((always_inline)) {
+    const int N = ka.p.N;
+    const int full_words = N >> 6, rem = N & 63;
+    const bool self_here = kw >= wbase && kw < wbase + MPL;
+    const int w_ph = full_words > wbase ? full_words : wbase;
+    Stateless z;
+    z.selfm = sgpr64(self_here ? (1ull << kb) : 0ull);
+    z.selfidx = sgpr32(self_here ? 2u * (uint32_t)(kw - wbase) : 0u);
+    z.phm = sgpr64((w_ph == full_words && rem) ? ~((1ull << rem) - 1ull) : ~0ull);
+    z.phidx = sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL);
+    return z;
+  };
 
   // bit of the target itself at the two forced sites; it is '1' at every other site of its list
-  const uint64_t sk_first = sgpr64(((rows[kw] >> kb) & 1ull) ? ~0ull : 0ull);
-  const uint64_t sk_last = sgpr64(((rows[(size_t)(L - 1) * stride + kw] >> kb) & 1ull) ? ~0ull : 0ull);
+  const uint64_t sk_first = sgpr64(((ka.rows[kw] >> kb) & 1ull) ? ~0ull : 0ull);
+  const uint64_t sk_last = sgpr64(((ka.rows[(size_t)(ka.p.L - 1) * stride + kw] >> kb) & 1ull) ? ~0ull : 0ull);
 
   const uint32_t lds_mine = (uint32_t)(uintptr_t)(stage + wbase * 64 + lane);
 
   // Stone payload (src/fast_painting.cpp:368-388,:573-592): every lane drops its states as floats into
   // LDS, then the workgroup streams the N floats out with coalesced stores; the target's own entry is
   // an exact zero already (:312,:507).
-  auto store_states = [&](float* __restrict__ dst) __attribute__((always_inline)) {
+  auto store_states = [&](float* __restrict__ dst, int N) __attribute__((always_inline)) {
     const uint32_t a = lds_mine;
     static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) { state_to_lds<decltype(ic)::value>(a); });
     swait();
@@ -431,14 +465,14 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(
   };
 
   // ---------------- forward (src/fast_painting.cpp:214-408) ----------------
-  {
+  if (pass == 0) {
     double acc = 0.0;
-    const double prior_mis = p.c.prior_mis, prior_match = p.c.prior_match;
+    const double prior_mis = ka.p.c.prior_mis, prior_match = ka.p.c.prior_match;
     static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       const int wi = wbase + i;
       const uint64_t w = rows_w[i];
-      const bool v = __builtin_amdgcn_inverse_ballot_w64(valid_mask(wi, N, k));
+      const bool v = __builtin_amdgcn_inverse_ballot_w64(valid_mask(wi, ka.p.N, k));
       const bool m = __builtin_amdgcn_inverse_ballot_w64(~w & sk_first);
       const double a = m ? prior_mis : prior_match;
       state_set<i>(v ? a : 0.0);
@@ -450,19 +484,22 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(
     int stone_j = 0;  // list index at which the next alpha stone is due (window 0 starts at site 0)
     auto emit = [&](int j, int s) __attribute__((always_inline)) {
       while (stone_j == j) {
-        uint8_t* rec = out + ((size_t)wcur * K + t) * R;
+        KArgsPtr q = rare_args();
+        const int N = q->p.N, W = q->p.W;
+        uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
         if (first_thread) {
-          put_u32(rec, (uint32_t)wb[wcur]);
-          put_u32(rec + 4, (uint32_t)(wb[wcur + 1] - 1));
+          put_u32(rec, (uint32_t)q->wb[wcur]);
+          put_u32(rec + 4, (uint32_t)(q->wb[wcur + 1] - 1));
           put_block_header(rec + 8, N, s, (float)ls);
         }
-        store_states(reinterpret_cast<float*>(rec + 32));
+        store_states(reinterpret_cast<float*>(rec + 32), N);
         wcur++;
-        stone_j = wcur < W ? __builtin_amdgcn_readfirstlane(bbj[wcur]) : -1;
+        stone_j = wcur < W ? __builtin_amdgcn_readfirstlane(q->bbj_all[(long long)t * W + wcur]) : -1;
       }
     };
     emit(0, 0);
-    const double rho = p.c.rho_theta, lo = p.c.lo, hi = p.c.hi;
+    const Stateless z = stateless();
+    const double rho = ka.p.c.rho_theta, lo = ka.p.c.lo, hi = ka.p.c.hi;
     int s_cur = __builtin_amdgcn_readfirstlane(dk[1]);  // nd >= 2: sites 0 and L-1 are always listed
     int s_next = __builtin_amdgcn_readfirstlane(dk[2 < nd ? 2 : nd - 1]);
     double coef_j = coef[0], nx_j = nx[0];  // terms of the gap before site j
@@ -471,7 +508,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(
     swait();
     for (int j = 1; j < nd; j++) {
       const double rx = S * coef_j;
-      write_stateless<MPL>(-rx, selfm, selfidx, phm, phidx);
+      write_stateless<MPL>(-rx, z.selfm, z.selfidx, z.phm, z.phidx);
       // scalars of site j+1 travel during this sweep: its successor in the list and the terms of the gap before it
       prefetch_site(dk + (j + 2 < nd ? j + 2 : nd - 1), coef + j, nx + j);
       const uint64_t skm = edge_select(j, nd - 1, sk_last);
@@ -512,34 +549,37 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(
   }
 
   // ---------------- backward (src/fast_painting.cpp:410-599) ----------------
-  {
-    const double theta_d = p.c.theta_d, ntheta_d = p.c.ntheta_d;
-    double ls = p.c.log_Nm1 - (double)nd * p.c.log_ntheta;
-    const uint64_t* row_last = rows_w + (size_t)(L - 1) * stride;
+  else {
+    const double theta_d = ka.p.c.theta_d, ntheta_d = ka.p.c.ntheta_d;
+    double ls = ka.p.c.log_Nm1 - (double)nd * ka.p.c.log_ntheta;
+    const uint64_t* row_last = rows_w + (size_t)(ka.p.L - 1) * stride;
     double acc = 0.0;
     static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       const int wi = wbase + i;
       const uint64_t w = row_last[i];
-      const bool v = __builtin_amdgcn_inverse_ballot_w64(valid_mask(wi, N, k));
+      const bool v = __builtin_amdgcn_inverse_ballot_w64(valid_mask(wi, ka.p.N, k));
       const bool m = __builtin_amdgcn_inverse_ballot_w64(~w & sk_last);
       state_set<i>(1.0);
       acc += v ? (m ? theta_d : ntheta_d) : 0.0;
     });
     double B = block_sum_regs<G>(acc, red, slot);
-    int wcur = W - 1;
-    int stone_j = __builtin_amdgcn_readfirstlane(bej[W - 1]);  // == nd-1: the last window ends at the last SNP
+    int wcur = ka.p.W - 1;
+    int stone_j = nd - 1;  // the last window ends at the last SNP
     // stones taken at the last SNP hold beta = 1 for every state, the target included (:427-432,:447-462)
     while (stone_j == nd - 1) {
-      uint8_t* rec = out + ((size_t)wcur * K + t) * R;
-      if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, L - 1, (float)ls);
+      KArgsPtr q = rare_args();
+      const int N = q->p.N;
+      uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
+      if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, q->p.L - 1, (float)ls);
       float* dst = reinterpret_cast<float*>(rec + 56 + (size_t)4 * N);
       for (int n = threadIdx.x; n < N; n += 64 * G) dst[n] = 1.0f;
       wcur--;
-      stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(bej[wcur]) : -1;
+      stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
     }
-    const double rho = p.c.rho_theta, lo = p.c.lo, hi = p.c.hi;
-    const double inv_nt = p.c.inv_ntheta_d, inv_t = p.c.inv_theta_d;
+    const Stateless z = stateless();
+    const double rho = ka.p.c.rho_theta, lo = ka.p.c.lo, hi = ka.p.c.hi;
+    const double inv_nt = ka.p.c.inv_ntheta_d, inv_t = ka.p.c.inv_theta_d;
     const double w_all = ntheta_d, w_mis = theta_d - ntheta_d;
     int s_cur = __builtin_amdgcn_readfirstlane(dk[nd - 2]);
     int s_prev = __builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]);
@@ -556,7 +596,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(
       const double aa = rx * inv_nt;
       const double bb = rx * inv_t - aa;
       const double c1 = (bb + aa) * rho;
-      write_stateless<MPL>(-aa, selfm, selfidx, phm, phidx);
+      write_stateless<MPL>(-aa, z.selfm, z.selfidx, z.phm, z.phidx);
       // scalars of the step to site j-1 travel during this sweep
       prefetch_site(dk + (j > 1 ? j - 2 : 0), coef + j, nx + j);
       const uint64_t skn = edge_select(j, nd - 2, sk_last);
@@ -603,11 +643,13 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(
         B = 1.0;
       }
       while (stone_j == j) {
-        uint8_t* rec = out + ((size_t)wcur * K + t) * R;
+        KArgsPtr q = rare_args();
+        const int N = q->p.N;
+        uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
         if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, s_cur, (float)ls);
-        store_states(reinterpret_cast<float*>(rec + 56 + (size_t)4 * N));
+        store_states(reinterpret_cast<float*>(rec + 56 + (size_t)4 * N), N);
         wcur--;
-        stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(bej[wcur]) : -1;
+        stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
       }
       s_cur = s_prev;
       s_prev = s_prev2;
@@ -630,16 +672,26 @@ inline hipError_t launch_regs_t(const PaintArgs& a, hipStream_t st)
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
       if (e != hipSuccess) return e;
     }
-    Scal s;
-    s.row_stride = a.row_stride;
-    s.N = a.N;
-    s.L = a.L;
-    s.W = a.W;
-    s.k_begin = a.k_begin;
-    s.K = a.K;
-    s.c = a.c;
-    hipLaunchKernelGGL((paint_kernel_r<MPL, G>), dim3(a.K), dim3(64 * G), lds_bytes, st, a.rows, a.dk, a.coef, a.nx,
-                       a.off, a.nd, a.bbj, a.bej, a.order, a.wb, a.out, s);
+    KArgs ka;
+    ka.rows = a.rows;
+    ka.dk_all = a.dk;
+    ka.coef_all = a.coef;
+    ka.nx_all = a.nx;
+    ka.off = a.off;
+    ka.nd_all = a.nd;
+    ka.bbj_all = a.bbj;
+    ka.bej_all = a.bej;
+    ka.order = a.order;
+    ka.wb = a.wb;
+    ka.out = a.out;
+    ka.p.row_stride = a.row_stride;
+    ka.p.N = a.N;
+    ka.p.L = a.L;
+    ka.p.W = a.W;
+    ka.p.k_begin = a.k_begin;
+    ka.p.K = a.K;
+    ka.p.c = a.c;
+    hipLaunchKernelGGL((paint_kernel_r<MPL, G>), dim3(2 * (unsigned)a.K), dim3(64 * G), lds_bytes, st, ka);
     return hipGetLastError();
   }
 }
