@@ -37,6 +37,7 @@ struct PaintArgs {
   const int32_t* order;    // [K] launch order (longest target first)
   const int32_t* wb;       // [W+1] window boundaries (device copy)
   uint8_t* out;            // [W][K][56+8N] records
+  uint64_t* trace;         // diagnostics (or null): 4 words per workgroup of the register-resident kernel
   int N, L, W, k_begin, K;
   PaintConsts c;
 };

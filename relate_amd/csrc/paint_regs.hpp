@@ -366,6 +366,24 @@ __device__ __forceinline__ double block_sum_regs(double x, double (*red)[G], int
   }
 }
 
+// The instruction arbiter of a SIMD serves the oldest wave first, so of the four waves that share a SIMD
+// the youngest would lag and run the end of its pass alone, at the issue rate of a single wave.  Every
+// wave therefore rotates its own priority with its progress (rank = its slot on the SIMD, i.e. its age
+// rank): all four see the same sequence of priorities and advance at the same average rate.
+// The backward pass has 4/3 of the work of the forward pass per site, so its waves (`bias` 1) move up
+// one level half of the time and the two kinds end closer together.
+__device__ __forceinline__ void rotate_priority(int rank, int j, int bias)
+{
+  int level = (rank + (j >> 5)) & 3;
+  if (bias && ((j >> 7) & 1) && level < 3) level++;
+  switch (level) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+}
+
 // ---- kernel ----------------------------------------------------------------------------------------
 // Kernel arguments as one struct, so that the rarely used ones can be fetched from the kernel-argument
 // segment where they are needed instead of occupying scalar registers across the sweeps.
@@ -381,6 +399,7 @@ struct KArgs {
   const int32_t* order;
   const int32_t* wb;
   uint8_t* out;
+  uint64_t* trace;
   Scal p;
 };
 typedef const __attribute__((address_space(4))) KArgs* KArgsPtr;
@@ -412,6 +431,8 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
   // the pair 2i, 2i+1 takes which pass follows the parity of the set bits of the block index, so that
   // every power-of-two stride of the dispatcher (XCDs, CUs, SIMDs) sees both kinds.
   const int pass = __builtin_popcount(blockIdx.x) & 1;
+  const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();
+  const int rank = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3;  // HW_ID.wave_id: slot of this wave on its SIMD
   const int t = __builtin_amdgcn_readfirstlane(ka.order[blockIdx.x >> 1]);
   const int k = ka.p.k_begin + t;
   const int lane = lane_id();
@@ -507,6 +528,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     sload4<kBufA, 0>(rp);
     swait();
     for (int j = 1; j < nd; j++) {
+      if ((j & 31) == 0) rotate_priority(rank, j, 0);
       const double rx = S * coef_j;
       write_stateless<MPL>(-rx, z.selfm, z.selfidx, z.phm, z.phidx);
       // scalars of site j+1 travel during this sweep: its successor in the list and the terms of the gap before it
@@ -590,6 +612,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     sload4<kBufC, 0>(rp_c);
     swait();
     for (int j = nd - 2; j >= 0; j--) {
+      if ((j & 31) == 0) rotate_priority(rank, j, 1);
       // beta' = (beta + mis'*b + a) * (mis' ? rho : 1), a = rx/(1-theta), b = rx/theta - a (:488-502), as
       // matching states: beta + a; mismatching states: fma(beta, rho, (b + a)*rho)
       const double rx = B * coef_j;
@@ -657,6 +680,17 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       rp_c = rp_p;
     }
   }
+  {
+    KArgsPtr q = rare_args();
+    if (q->trace && threadIdx.x == 0) {
+      uint64_t* tr = q->trace + (size_t)4 * blockIdx.x;
+      const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      tr[0] = ((uint64_t)xcc << 32) | hw;
+      tr[1] = trace_t0;
+      tr[2] = __builtin_amdgcn_s_memrealtime();
+      tr[3] = (uint64_t)pass | ((uint64_t)nd << 8);
+    }
+  }
 }
 
 template <int MPL, int G>
@@ -684,6 +718,7 @@ inline hipError_t launch_regs_t(const PaintArgs& a, hipStream_t st)
     ka.order = a.order;
     ka.wb = a.wb;
     ka.out = a.out;
+    ka.trace = a.trace;
     ka.p.row_stride = a.row_stride;
     ka.p.N = a.N;
     ka.p.L = a.L;

@@ -130,6 +130,7 @@ struct relate_plan {
   int k_begin = 0, K = 0;
   double theta_p = 0, theta_d = 0;
   DevBuf nd, off, dk, coef, nx, bbj, bej, order;
+  DevBuf trace;
   std::vector<int32_t> h_nd;
   std::vector<int64_t> h_off;
   int64_t sum_nd = 0;
@@ -204,7 +205,7 @@ void relate_plan_destroy(relate_plan* p)
   if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
   if (!p->packed_borrowed) p->packed.release();
   for (DevBuf* b : {&p->seq_own, &p->r_own, &p->wb_dev, &p->nd, &p->off, &p->dk, &p->coef, &p->nx, &p->bbj, &p->bej,
-                    &p->order})
+                    &p->order, &p->trace})
     b->release();
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
@@ -414,10 +415,28 @@ int relate_plan_paint(relate_plan* p, void* d_out, void* stream)
   a.k_begin = p->k_begin;
   a.K = p->K;
   a.c = make_consts(p->N, p->theta_p, p->theta_d);
+  a.trace = nullptr;
+  // Diagnostics: RELATE_TRACE=<file> makes the register-resident kernel record, per workgroup, where it
+  // ran and when it started and ended (4 x u64: hardware id, start, end in 100 MHz ticks, pass | nd << 8).
+  const char* trace_path = p->variant == 2 ? std::getenv("RELATE_TRACE") : nullptr;
+  const size_t trace_words = (size_t)8 * p->K;
+  if (trace_path && *trace_path) {
+    if (int rc = p->trace.reserve(sizeof(uint64_t) * trace_words)) return rc;
+    a.trace = p->trace.as<uint64_t>();
+  }
   HIP_TRY(hipEventRecord(p->ev[4], st));
   HIP_TRY(relate::launch_paint(a, p->geo, p->variant, st));
   HIP_TRY(hipEventRecord(p->ev[5], st));
   p->have_paint = true;
+  if (a.trace) {
+    std::vector<uint64_t> h(trace_words);
+    HIP_TRY(hipMemcpyAsync(h.data(), a.trace, sizeof(uint64_t) * trace_words, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (FILE* f = std::fopen(trace_path, "wb")) {
+      std::fwrite(h.data(), sizeof(uint64_t), trace_words, f);
+      std::fclose(f);
+    }
+  }
   return RELATE_OK;
 }
 
