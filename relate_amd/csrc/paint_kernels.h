@@ -24,12 +24,22 @@ struct PaintConsts {
   double lo, hi;        // rescale thresholds 1e-10, 1e10
 };
 
+// Per derived site j of a target, for the register-resident kernel: the two per-gap terms and the list
+// entries two steps ahead in either direction (what a sweep prefetches for the site after the next).
+struct SiteRec {
+  double coef;      // r_prob/((1-r_prob)(N-1)) of gap j
+  double nx;        // nor_x_theta of gap j
+  int32_t dk_fwd2;  // dk[min(j+2, nd-1)]
+  int32_t dk_bwd2;  // dk[max(j-2, 0)]
+};
+
 struct PaintArgs {
   const uint64_t* rows;    // [L][row_stride] bit rows: bit (n&63) of word n>>6 = seq[s][n]=='1'
   int row_stride;          // in 64-bit words, multiple of 8
   const int32_t* dk;       // flat derived-site lists
   const double* coef;      // flat r_prob/((1-r_prob)(N-1)) per derived site
   const double* nx;        // flat nor_x_theta per derived site
+  const SiteRec* rec;      // the same interleaved (variant 2 reads this instead of coef / nx)
   const int64_t* off;      // [K] start of target t's lists
   const int32_t* nd;       // [K] number of derived sites
   const int32_t* bbj;      // [K][W] index into the list where window w's alpha stone is taken
@@ -59,9 +69,10 @@ hipError_t launch_count_derived(const uint64_t* d_cols, int col_stride, int L, i
                                 hipStream_t st);
 hipError_t launch_fill_sites(const uint64_t* d_cols, int col_stride, int L, int k_begin, int K, const int64_t* d_off,
                              int32_t* d_dk, hipStream_t st);
+// writes coef / nx (if not null) and rec (if not null)
 hipError_t launch_site_terms(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int max_nd,
                              const double* d_r, int L, const PaintConsts& c, double* d_coef, double* d_nx,
-                             hipStream_t st);
+                             SiteRec* d_rec, hipStream_t st);
 hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int W,
                                 const int32_t* d_wb, int32_t* d_bbj, int32_t* d_bej, hipStream_t st);
 // variant: 0 = plain HIP recursion, 1 = exec-masked inline-asm recursion, 2 = register-resident recursion

@@ -141,7 +141,8 @@ __global__ void __launch_bounds__(256) fill_sites_kernel(const uint64_t* __restr
 __global__ void __launch_bounds__(256) site_terms_kernel(const int32_t* __restrict__ dk, const int64_t* __restrict__ off,
                                                          const int32_t* __restrict__ nd, const double* __restrict__ r,
                                                          double log_ntheta, double log_small, double Nm1,
-                                                         double* __restrict__ coef, double* __restrict__ nx)
+                                                         double* __restrict__ coef, double* __restrict__ nx,
+                                                         SiteRec* __restrict__ rec)
 {
   const int t = blockIdx.y;
   const int n = nd[t];
@@ -157,8 +158,19 @@ __global__ void __launch_bounds__(256) site_terms_kernel(const int32_t* __restri
       rp = 0.99;
       nxv = log_small + log_ntheta;
     }
-    coef[o + j] = rp / ((1.0 - rp) * Nm1);
-    nx[o + j] = nxv;
+    const double cf = rp / ((1.0 - rp) * Nm1);
+    if (coef) {
+      coef[o + j] = cf;
+      nx[o + j] = nxv;
+    }
+    if (rec) {
+      SiteRec q;
+      q.coef = cf;
+      q.nx = nxv;
+      q.dk_fwd2 = dk[o + (j + 2 < n ? j + 2 : n - 1)];
+      q.dk_bwd2 = dk[o + (j > 1 ? j - 2 : 0)];
+      rec[o + j] = q;
+    }
   }
 }
 
@@ -452,14 +464,14 @@ hipError_t launch_fill_sites(const uint64_t* d_cols, int col_stride, int L, int 
 
 hipError_t launch_site_terms(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int max_nd,
                              const double* d_r, int L, const PaintConsts& c, double* d_coef, double* d_nx,
-                             hipStream_t st)
+                             SiteRec* d_rec, hipStream_t st)
 {
   (void)L;
   int bx = (max_nd + 255) / 256;
   if (bx > 64) bx = 64;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(site_terms_kernel, dim3(bx, K), dim3(256), 0, st, d_dk, d_off, d_nd, d_r, c.log_ntheta,
-                     c.log_small, c.Nm1, d_coef, d_nx);
+                     c.log_small, c.Nm1, d_coef, d_nx, d_rec);
   return hipGetLastError();
 }
 
@@ -504,7 +516,7 @@ hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStr
     return hipErrorInvalidValue;
   }
   if (variant == 2) {
-    if (g.G * g.MPL > a.row_stride) return hipErrorInvalidValue;
+    if (g.G * g.MPL > a.row_stride || !a.rec) return hipErrorInvalidValue;
     switch (g.G) {
       case 1: return launch_paint_regs_g1(a, g.MPL, st);
       case 2: return launch_paint_regs_g2(a, g.MPL, st);

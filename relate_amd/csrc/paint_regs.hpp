@@ -33,23 +33,26 @@ using namespace dev;
 
 // ---- register map -------------------------------------------------------------------------------
 #define RELATE_CV 48  // compiler: v0..v47
-#define RELATE_CS 64  // compiler: s0..s63
-// amdgpu_num_sgpr counts the 8 special registers (VCC, FLAT_SCRATCH, XNACK_MASK) on top of s0..s63
-#define RELATE_CS_ATTR 72
+#define RELATE_CS 60  // compiler: s0..s59
+// amdgpu_num_sgpr counts the 8 special registers (VCC, FLAT_SCRATCH, XNACK_MASK) on top of s0..s59
+#define RELATE_CS_ATTR 68
 // amdgpu_num_vgpr is doubled by the gfx90a+ back end (unified VGPR/AGPR file); no AGPRs are used here
 #define RELATE_CV_ATTR 24
 constexpr int kCV = RELATE_CV, kCS = RELATE_CS;
 static_assert(RELATE_CS_ATTR == RELATE_CS + 8 && 2 * RELATE_CV_ATTR == RELATE_CV, "register limits");
 constexpr int kX = kCV;       // v[kX:kX+1]   reduction operand
 constexpr int kT = kCV + 2;   // v[kT:kT+1]   scratch pair
-constexpr int kA0 = kCV + 4;  // v[kA0 + 2i : kA0 + 2i + 1] = state of word i
+constexpr int kLo = kCV + 4;  // v[kLo:kLo+1] lower rescale threshold, v[kHi:kHi+1] upper
+constexpr int kHi = kCV + 6;
+constexpr int kA0 = kCV + 8;  // v[kA0 + 2i : kA0 + 2i + 1] = state of word i
 constexpr int kBufA = kCS, kBufB = kCS + 8, kBufC = kCS + 16, kBufD = kCS + 24;  // 4 x 8 SGPRs of row words
 constexpr int kRL = kBufB;      // readlane results of the reduction (the B buffer is idle then)
-constexpr int kDkN = kCS + 32;  // prefetched list entry
-constexpr int kCnt = kCS + 33;  // loop counter of the padding-lane writes
-constexpr int kCoefN = kCS + 34, kNxN = kCS + 36;  // prefetched per-gap terms (pairs)
+constexpr int kCoefN = kCS + 32, kNxN = kCS + 34;  // prefetched per-gap terms (pairs; one 4-aligned quad)
+constexpr int kDkN = kCS + 36;  // prefetched list entry
+constexpr int kCnt = kCS + 37;  // loop counter of the padding-lane writes
+constexpr int kRec = kCS + 38;  // s[kRec:kRec+1] running pointer into the site records
 constexpr int kMaxMPL = (256 - kA0) / 2;
-static_assert(kNxN + 1 <= 101, "SGPR map");
+static_assert(kRec + 1 <= 101 && kCoefN % 4 == 0 && kBufA % 4 == 0, "SGPR map");
 
 #define RELATE_REGS_ATTR __attribute__((amdgpu_num_vgpr(RELATE_CV_ATTR), amdgpu_num_sgpr(RELATE_CS_ATTR)))
 
@@ -65,23 +68,23 @@ __device__ __forceinline__ void static_for(F&& f)
 // Tells the compiler which registers the asm statements use by number: it then counts them in the
 // kernel's register budget and keeps its own SGPR-spill lanes out of them (the spill VGPRs are taken
 // from the registers it believes unused, whatever amdgpu_num_vgpr says).  Clobber names must be
-// literals, hence the cumulative lists: RELATE_VCLOB_<MPL> = v48 .. v[kA0 + 2*MPL - 1].
-#define RELATE_VCLOB_4 "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59"
-#define RELATE_VCLOB_8 RELATE_VCLOB_4, "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67"
-#define RELATE_VCLOB_12 RELATE_VCLOB_8, "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75"
-#define RELATE_VCLOB_16 RELATE_VCLOB_12, "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83"
-#define RELATE_VCLOB_20 RELATE_VCLOB_16, "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91"
-#define RELATE_VCLOB_24 RELATE_VCLOB_20, "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99"
-#define RELATE_VCLOB_28 RELATE_VCLOB_24, "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107"
-#define RELATE_VCLOB_32 RELATE_VCLOB_28, "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115"
-#define RELATE_VCLOB_36 RELATE_VCLOB_32, "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123"
-#define RELATE_VCLOB_40 RELATE_VCLOB_36, "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131"
-#define RELATE_VCLOB_48 RELATE_VCLOB_40, "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147"
-#define RELATE_VCLOB_56 RELATE_VCLOB_48, "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163"
-#define RELATE_VCLOB_64 RELATE_VCLOB_56, "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179"
-#define RELATE_VCLOB_72 RELATE_VCLOB_64, "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195"
-#define RELATE_VCLOB_80 RELATE_VCLOB_72, "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211"
-#define RELATE_SCLOB "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101"
+// literals, hence the cumulative lists: RELATE_VCLOB_<MPL> = v48 .. v[kA0 + 2*MPL - 1], RELATE_SCLOB = s60 .. s101.
+#define RELATE_VCLOB_4 "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
+#define RELATE_VCLOB_8 RELATE_VCLOB_4, "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71"
+#define RELATE_VCLOB_12 RELATE_VCLOB_8, "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
+#define RELATE_VCLOB_16 RELATE_VCLOB_12, "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87"
+#define RELATE_VCLOB_20 RELATE_VCLOB_16, "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
+#define RELATE_VCLOB_24 RELATE_VCLOB_20, "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103"
+#define RELATE_VCLOB_28 RELATE_VCLOB_24, "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"
+#define RELATE_VCLOB_32 RELATE_VCLOB_28, "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119"
+#define RELATE_VCLOB_36 RELATE_VCLOB_32, "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define RELATE_VCLOB_40 RELATE_VCLOB_36, "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135"
+#define RELATE_VCLOB_48 RELATE_VCLOB_40, "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151"
+#define RELATE_VCLOB_56 RELATE_VCLOB_48, "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167"
+#define RELATE_VCLOB_64 RELATE_VCLOB_56, "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183"
+#define RELATE_VCLOB_72 RELATE_VCLOB_64, "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199"
+#define RELATE_VCLOB_80 RELATE_VCLOB_72, "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"
+#define RELATE_SCLOB "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101"
 template <int MPL>
 __device__ __forceinline__ void claim_registers();
 #define RELATE_CLAIM(M)                                                \
@@ -106,7 +109,7 @@ RELATE_CLAIM(64)
 RELATE_CLAIM(72)
 RELATE_CLAIM(80)
 #undef RELATE_CLAIM
-static_assert(kCV == 48 && kA0 == 52 && kCS == 64, "the clobber lists above are written for this register map");
+static_assert(kCV == 48 && kA0 == 56 && kCS == 60, "the clobber lists above are written for this register map");
 
 // A wave-uniform value as an SGPR (the compiler's readfirstlane may be folded into a VGPR copy).
 __device__ __forceinline__ uint32_t sgpr32(uint32_t x)
@@ -144,16 +147,53 @@ __device__ __forceinline__ void scopy8()
       "s_mov_b64 s[%0+4:%0+5], s[%1+4:%1+5]\n\ts_mov_b64 s[%0+6:%0+7], s[%1+6:%1+7]" ::"n"(DST),
       "n"(SRC));
 }
-// Per-site scalars of the next site, fetched during the sweep of this one.
-__device__ __forceinline__ void prefetch_site(const int32_t* pdk, const double* pcoef, const double* pnx)
+// The record of a list entry (SiteRec: coef, nx, dk_fwd2, dk_bwd2), fetched during a sweep for the site
+// after it.  The two list entries land in s[kDkN] (forward) and s[kCnt] (backward); the latter doubles
+// as the loop counter of write_stateless(), which has finished before the fetch is issued.
+template <bool FWD>
+__device__ __forceinline__ void prefetch_site()
 {
-  asm volatile(
-      "s_load_dword s[%3], %0, 0\n\t"
-      "s_load_dwordx2 s[%4:%4+1], %1, 0\n\t"
-      "s_load_dwordx2 s[%5:%5+1], %2, 0" ::"s"(pdk),
-      "s"(pcoef), "s"(pnx), "n"(kDkN), "n"(kCoefN), "n"(kNxN)
-      : "memory");
+  // through the running pointer s[kRec:kRec+1], which then moves on to the next record of the pass
+  if constexpr (FWD)
+    asm volatile(
+        "s_load_dwordx4 s[%0:%0+3], s[%2:%2+1], 0\n\t"
+        "s_load_dwordx2 s[%1:%1+1], s[%2:%2+1], 16\n\t"
+        "s_add_u32 s[%2], s[%2], 24\n\t"
+        "s_addc_u32 s[%2+1], s[%2+1], 0" ::"n"(kCoefN),
+        "n"(kDkN), "n"(kRec)
+        : "memory", "scc");
+  else
+    asm volatile(
+        "s_load_dwordx4 s[%0:%0+3], s[%2:%2+1], 0\n\t"
+        "s_load_dwordx2 s[%1:%1+1], s[%2:%2+1], 16\n\t"
+        "s_sub_u32 s[%2], s[%2], 24\n\t"
+        "s_subb_u32 s[%2+1], s[%2+1], 0" ::"n"(kCoefN),
+        "n"(kDkN), "n"(kRec)
+        : "memory", "scc");
 }
+__device__ __forceinline__ void set_site_pointer(const SiteRec* q)
+{
+  asm volatile("s_mov_b64 s[%1:%1+1], %0" ::"s"(q), "n"(kRec));
+}
+// Rescale thresholds into their registers; out_of_range(S) = S < lo || S > hi as a lane mask (all or none:
+// S is the same in every lane).
+__device__ __forceinline__ void set_thresholds(double lo, double hi)
+{
+  asm volatile("v_mov_b64 v[%2:%2+1], %0\n\tv_mov_b64 v[%3:%3+1], %1" ::"v"(lo), "v"(hi), "n"(kLo), "n"(kHi));
+}
+__device__ __forceinline__ bool out_of_range(double S)
+{
+  uint64_t m;
+  asm volatile(
+      "v_cmp_lt_f64 vcc, %1, v[%2:%2+1]\n\t"
+      "v_cmp_gt_f64 %0, %1, v[%3:%3+1]\n\t"
+      "s_or_b64 %0, %0, vcc"
+      : "=s"(m)
+      : "v"(S), "n"(kLo), "n"(kHi)
+      : "vcc", "scc");
+  return m != 0;
+}
+template <bool FWD>
 __device__ __forceinline__ void fetched_site(int& s, double& coef, double& nx)
 {
   // s_mov into compiler registers: from here on they are ordinary values
@@ -162,10 +202,11 @@ __device__ __forceinline__ void fetched_site(int& s, double& coef, double& nx)
       "s_mov_b32 %0, s[%5]\n\ts_mov_b32 %1, s[%6]\n\ts_mov_b32 %2, s[%6+1]\n\ts_mov_b32 %3, s[%7]\n\t"
       "s_mov_b32 %4, s[%7+1]"
       : "=s"(s), "=s"(lo0), "=s"(hi0), "=s"(lo1), "=s"(hi1)
-      : "n"(kDkN), "n"(kCoefN), "n"(kNxN));
+      : "n"(FWD ? kDkN : kCnt), "n"(kCoefN), "n"(kNxN));
   coef = __hiloint2double((int)hi0, (int)lo0);
   nx = __hiloint2double((int)hi1, (int)lo1);
 }
+static_assert(kCnt == kDkN + 1 && kNxN == kCoefN + 2 && sizeof(SiteRec) == 24, "record layout against the SGPR map");
 
 // ---- state block -----------------------------------------------------------------------------------
 template <int I>
@@ -390,8 +431,7 @@ __device__ __forceinline__ void rotate_priority(int rank, int j, int bias)
 struct KArgs {
   const uint64_t* rows;
   const int32_t* dk_all;
-  const double* coef_all;
-  const double* nx_all;
+  const SiteRec* rec_all;
   const int64_t* off;
   const int32_t* nd_all;
   const int32_t* bbj_all;
@@ -442,8 +482,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
   const int nd = __builtin_amdgcn_readfirstlane(ka.nd_all[t]);
   const long long o = ka.off[t];
   const int32_t* __restrict__ dk = ka.dk_all + o;
-  const double* __restrict__ coef = ka.coef_all + o;
-  const double* __restrict__ nx = ka.nx_all + o;
+  const SiteRec* __restrict__ rec = ka.rec_all + o;
   const int kw = k >> 6, kb = k & 63;
   const bool first_thread = threadIdx.x == 0;
   const uint64_t* rows_w = ka.rows + wbase;  // the words of this wave start here in every row
@@ -520,10 +559,12 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     };
     emit(0, 0);
     const Stateless z = stateless();
-    const double rho = ka.p.c.rho_theta, lo = ka.p.c.lo, hi = ka.p.c.hi;
+    const double rho = ka.p.c.rho_theta;
+    set_thresholds(ka.p.c.lo, ka.p.c.hi);
     int s_cur = __builtin_amdgcn_readfirstlane(dk[1]);  // nd >= 2: sites 0 and L-1 are always listed
     int s_next = __builtin_amdgcn_readfirstlane(dk[2 < nd ? 2 : nd - 1]);
-    double coef_j = coef[0], nx_j = nx[0];  // terms of the gap before site j
+    double coef_j = rec[0].coef, nx_j = rec[0].nx;  // terms of the gap before site j
+    set_site_pointer(rec + 1);
     const uint64_t* rp = rows_w + (size_t)s_cur * stride;
     sload4<kBufA, 0>(rp);
     swait();
@@ -532,7 +573,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       const double rx = S * coef_j;
       write_stateless<MPL>(-rx, z.selfm, z.selfidx, z.phm, z.phidx);
       // scalars of site j+1 travel during this sweep: its successor in the list and the terms of the gap before it
-      prefetch_site(dk + (j + 2 < nd ? j + 2 : nd - 1), coef + j, nx + j);
+      prefetch_site<true>();
       const uint64_t skm = edge_select(j, nd - 1, sk_last);
       ls += nx_j;
       double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
@@ -553,8 +594,8 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       if constexpr (NB & 1) scopy8<kBufA, kBufB>();
       S = block_sum_regs<G>((c0 + c1) + (c2 + c3), red, slot);
       int s_next2;
-      fetched_site(s_next2, coef_j, nx_j);
-      if (S < lo || S > hi) {
+      fetched_site<true>(s_next2, coef_j, nx_j);
+      if (out_of_range(S)) {
         const double inv = 1.0 / S;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
           const double f = inv;
@@ -600,12 +641,14 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
     }
     const Stateless z = stateless();
-    const double rho = ka.p.c.rho_theta, lo = ka.p.c.lo, hi = ka.p.c.hi;
+    const double rho = ka.p.c.rho_theta;
+    set_thresholds(ka.p.c.lo, ka.p.c.hi);
     const double inv_nt = ka.p.c.inv_ntheta_d, inv_t = ka.p.c.inv_theta_d;
     const double w_all = ntheta_d, w_mis = theta_d - ntheta_d;
     int s_cur = __builtin_amdgcn_readfirstlane(dk[nd - 2]);
     int s_prev = __builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]);
-    double coef_j = coef[nd - 1], nx_j = nx[nd - 1];  // terms used by the step to site j: index j + 1
+    double coef_j = rec[nd - 1].coef, nx_j = rec[nd - 1].nx;  // terms used by the step to site j: index j + 1
+    set_site_pointer(rec + (nd - 2));
     const uint64_t* rp_n = row_last;
     const uint64_t* rp_c = rows_w + (size_t)s_cur * stride;
     sload4<kBufA, 0>(rp_n);
@@ -621,7 +664,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       const double c1 = (bb + aa) * rho;
       write_stateless<MPL>(-aa, z.selfm, z.selfidx, z.phm, z.phidx);
       // scalars of the step to site j-1 travel during this sweep
-      prefetch_site(dk + (j > 1 ? j - 2 : 0), coef + j, nx + j);
+      prefetch_site<false>();
       const uint64_t skn = edge_select(j, nd - 2, sk_last);
       const uint64_t skc = edge_select(j, 0, sk_first);
       ls += nx_j;
@@ -655,8 +698,8 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       // B = (1-theta) * sum over matching states + theta * sum over mismatching states (:509-517)
       B = block_sum_regs<G>(w_all * ((c.a0 + c.a1) + (c.a2 + c.a3)) + w_mis * ((c.m0 + c.m1) + (c.m2 + c.m3)), red, slot);
       int s_prev2;
-      fetched_site(s_prev2, coef_j, nx_j);
-      if (B < lo || B > hi) {
+      fetched_site<false>(s_prev2, coef_j, nx_j);
+      if (out_of_range(B)) {
         const double inv = 1.0 / B;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
           const double f = inv;
@@ -709,8 +752,7 @@ inline hipError_t launch_regs_t(const PaintArgs& a, hipStream_t st)
     KArgs ka;
     ka.rows = a.rows;
     ka.dk_all = a.dk;
-    ka.coef_all = a.coef;
-    ka.nx_all = a.nx;
+    ka.rec_all = a.rec;
     ka.off = a.off;
     ka.nd_all = a.nd;
     ka.bbj_all = a.bbj;

@@ -115,7 +115,7 @@ int check_windows(int L, int W, const int32_t* wb)
 struct relate_plan {
   int device = 0;
   hipStream_t own_stream = nullptr;
-  int variant = 1, prefer_waves = 0;
+  int variant = 2, prefer_waves = 0;
   // chunk
   int N = 0, L = 0, W = 0;
   int row_stride = 0, col_stride = 0;
@@ -130,7 +130,7 @@ struct relate_plan {
   int k_begin = 0, K = 0;
   double theta_p = 0, theta_d = 0;
   DevBuf nd, off, dk, coef, nx, bbj, bej, order;
-  DevBuf trace;
+  DevBuf trace, rec;
   std::vector<int32_t> h_nd;
   std::vector<int64_t> h_off;
   int64_t sum_nd = 0;
@@ -205,7 +205,7 @@ void relate_plan_destroy(relate_plan* p)
   if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
   if (!p->packed_borrowed) p->packed.release();
   for (DevBuf* b : {&p->seq_own, &p->r_own, &p->wb_dev, &p->nd, &p->off, &p->dk, &p->coef, &p->nx, &p->bbj, &p->bej,
-                    &p->order, &p->trace})
+                    &p->order, &p->trace, &p->rec})
     b->release();
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
@@ -222,6 +222,8 @@ int relate_plan_configure(relate_plan* p, int variant, int waves_per_target)
     return fail(RELATE_EINVAL, "waves_per_target must be 0, 1, 2, 4 or 8");
   p->variant = variant;
   p->prefer_waves = waves_per_target;
+  p->K = 0;  // what prepare leaves behind depends on the variant: prepare again before the next paint
+  p->have_prepare = false;
   return RELATE_OK;
 }
 
@@ -366,8 +368,13 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   if (int rc = p->off.reserve(sizeof(int64_t) * (size_t)K)) return rc;
   if (int rc = p->order.reserve(sizeof(int32_t) * (size_t)K)) return rc;
   if (int rc = p->dk.reserve(sizeof(int32_t) * (size_t)total)) return rc;
-  if (int rc = p->coef.reserve(sizeof(double) * (size_t)total)) return rc;
-  if (int rc = p->nx.reserve(sizeof(double) * (size_t)total)) return rc;
+  const bool records = p->variant == 2;  // the register-resident kernel reads interleaved site records
+  if (records) {
+    if (int rc = p->rec.reserve(sizeof(relate::SiteRec) * (size_t)total)) return rc;
+  } else {
+    if (int rc = p->coef.reserve(sizeof(double) * (size_t)total)) return rc;
+    if (int rc = p->nx.reserve(sizeof(double) * (size_t)total)) return rc;
+  }
   if (int rc = p->bbj.reserve(sizeof(int32_t) * (size_t)K * W)) return rc;
   if (int rc = p->bej.reserve(sizeof(int32_t) * (size_t)K * W)) return rc;
   HIP_TRY(hipMemcpyAsync(p->off.p, p->h_off.data(), sizeof(int64_t) * (size_t)K, hipMemcpyHostToDevice, st));
@@ -375,7 +382,8 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   HIP_TRY(relate::launch_fill_sites(p->d_cols, p->col_stride, p->L, k_begin, K, p->off.as<int64_t>(),
                                     p->dk.as<int32_t>(), st));
   HIP_TRY(relate::launch_site_terms(p->dk.as<int32_t>(), p->off.as<int64_t>(), p->nd.as<int32_t>(), K, max_nd, p->d_r,
-                                    p->L, c, p->coef.as<double>(), p->nx.as<double>(), st));
+                                    p->L, c, records ? nullptr : p->coef.as<double>(), records ? nullptr : p->nx.as<double>(),
+                                    records ? p->rec.as<relate::SiteRec>() : nullptr, st));
   HIP_TRY(relate::launch_window_stones(p->dk.as<int32_t>(), p->off.as<int64_t>(), p->nd.as<int32_t>(), K, W,
                                        p->wb_dev.as<int32_t>(), p->bbj.as<int32_t>(), p->bej.as<int32_t>(), st));
   HIP_TRY(hipEventRecord(p->ev[3], st));
@@ -402,6 +410,7 @@ int relate_plan_paint(relate_plan* p, void* d_out, void* stream)
   a.dk = p->dk.as<int32_t>();
   a.coef = p->coef.as<double>();
   a.nx = p->nx.as<double>();
+  a.rec = p->rec.as<relate::SiteRec>();
   a.off = p->off.as<int64_t>();
   a.nd = p->nd.as<int32_t>();
   a.bbj = p->bbj.as<int32_t>();
