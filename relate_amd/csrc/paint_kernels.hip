@@ -406,6 +406,10 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
   const int mpl_max = tab[ntab - 1];
   int G = 1;
   if (prefer_waves == 2 || prefer_waves == 4 || prefer_waves == 8) G = prefer_waves;
+  // The register-resident kernel is fastest with at most 32 states per lane (120 VGPRs: four waves per
+  // SIMD); measured on MI355X: N=2000 best with 1 wave per target, N=5008 with 4.
+  if (variant == 2 && prefer_waves == 0)
+    while (G < maxG && (M + G - 1) / G > 32) G *= 2;
   if (G > maxG) G = maxG;
   while (G < maxG && (M + G - 1) / G > mpl_max) G *= 2;
   const int need = (M + G - 1) / G;
@@ -418,7 +422,7 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
   if (variant != 0 && G == 8 && MPL == 80) MPL = 0;  // stone staging would exceed the LDS of a CU
   // the register-resident kernel reads G*MPL words of every row and needs the padding bits of all of them
   if (variant == 2 && MPL > 0 && G * MPL > row_stride_words(N)) {
-    if (prefer_waves > 1) return choose_geometry(N, prefer_waves / 2, variant);
+    if (G > 1) return choose_geometry(N, G / 2, variant);
     MPL = 0;
   }
   return {G, MPL};  // MPL == 0: N too large for this variant

@@ -228,14 +228,16 @@ __device__ __forceinline__ void state_to_lds(uint32_t lds_addr)
                : "memory");
 }
 
-// Lanes without a state <- v: the target's own lane (selfm = its bit, or 0 if its word belongs to
+// Lanes without a state <- -(x*y): the target's own lane (selfm = its bit, or 0 if its word belongs to
 // another wave; selfidx = 2 * local word) and every lane from the first padding lane of the wave on
-// (phm = lanes of that word, phidx = 2 * its local word; 2*MPL if the wave has none).
+// (phm = lanes of that word, phidx = 2 * its local word; 2*MPL if the wave has none).  x*y is what the
+// sweep adds to these lanes (the product rounds like the caller's own x*y, so the sum is an exact zero).
 template <int MPL>
-__device__ __forceinline__ void write_stateless(double v, uint64_t selfm, uint32_t selfidx, uint64_t phm, uint32_t phidx)
+__device__ __forceinline__ void write_stateless(double x, double y, uint64_t selfm, uint32_t selfidx, uint64_t phm,
+                                                uint32_t phidx)
 {
   asm volatile(
-      "v_mov_b64 v[%[t]:%[t]+1], %[v]\n\t"
+      "v_mul_f64 v[%[t]:%[t]+1], %[x], -%[y]\n\t"
       "s_mov_b64 exec, %[selfm]\n\t"
       "s_set_gpr_idx_on %[selfidx], 8\n\t"
       "s_nop 1\n\t"
@@ -259,7 +261,7 @@ __device__ __forceinline__ void write_stateless(double v, uint64_t selfm, uint32
       ".Lws_done%=:\n\t"
       "s_mov_b64 exec, -1"
       :
-      : [v] "v"(v), [selfm] "s"(selfm), [selfidx] "s"(selfidx), [phm] "s"(phm), [phidx] "s"(phidx), [t] "n"(kT),
+      : [x] "v"(x), [y] "v"(y), [selfm] "s"(selfm), [selfidx] "s"(selfidx), [phm] "s"(phm), [phidx] "s"(phidx), [t] "n"(kT),
         [a0] "n"(kA0), [cnt] "n"(kCnt), [end] "n"(2 * MPL)
       : "scc", "memory");
 }
@@ -270,32 +272,40 @@ __device__ __forceinline__ void write_stateless(double v, uint64_t selfm, uint32
 
 #define RELATE_FWD_ADD(i) "v_add_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[rx]\n\t"
 #define RELATE_FWD_MUL(i) "s_andn2_b64 exec, %[sk], " RELATE_W(s, i) "\n\tv_mul_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[rho]\n\t"
-#define RELATE_FWD_ACC(i) "v_add_f64 %[c" #i "], %[c" #i "], " RELATE_A(i) "\n\t"
+#define RELATE_FWD_ACC(c, i) "v_add_f64 %[" #c "], %[" #c "], " RELATE_A(i) "\n\t"
+#define RELATE_FWD_SET(c, i) "v_mov_b64 %[" #c "], " RELATE_A(i) "\n\t"
 
-// forward sweep over NW (1..4) words: states kA0+2*W0.., row words in s[SB..]
-template <int W0, int SB, int NW>
-__device__ __forceinline__ void fwd_batch(double& c0, double& c1, double& c2, double& c3, double rx, double rho, uint64_t sk)
+// forward sweep over NW (1..4) words: states kA0+2*W0.., row words in s[SB..]; the sums of the new
+// states go to two accumulators, which the first batch of a site initialises (FIRST)
+template <int W0, int SB, int NW, bool FIRST>
+__device__ __forceinline__ void fwd_batch(double& c0, double& c1, double rx, double rho, uint64_t sk)
 {
+  static_assert(!FIRST || NW >= 2, "the first batch initialises both accumulators");
 #define RELATE_FWD_OPS                                                                                         \
-  : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3)                                                 \
+  : [c0] "+v"(c0), [c1] "+v"(c1)                                                                               \
   : [rx] "v"(rx), [rho] "v"(rho), [sk] "s"(sk), [r] "n"(kA0 + 2 * W0), [s] "n"(SB)                             \
   : "scc"
-  if constexpr (NW == 4)
+  if constexpr (NW == 4 && FIRST)
     asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2) RELATE_FWD_ADD(3)
                  RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2) RELATE_FWD_MUL(3)
                  "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_ACC(0) RELATE_FWD_ACC(1) RELATE_FWD_ACC(2) RELATE_FWD_ACC(3) RELATE_FWD_OPS);
+                 RELATE_FWD_SET(c0, 0) RELATE_FWD_SET(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_ACC(c1, 3) RELATE_FWD_OPS);
+  else if constexpr (NW == 4)
+    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2) RELATE_FWD_ADD(3)
+                 RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2) RELATE_FWD_MUL(3)
+                 "s_mov_b64 exec, -1\n\t"
+                 RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_ACC(c1, 3) RELATE_FWD_OPS);
   else if constexpr (NW == 3)
     asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2)
                  RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2)
                  "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_ACC(0) RELATE_FWD_ACC(1) RELATE_FWD_ACC(2) RELATE_FWD_OPS);
+                 RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_OPS);
   else if constexpr (NW == 2)
     asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_MUL(0) RELATE_FWD_MUL(1)
                  "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_ACC(0) RELATE_FWD_ACC(1) RELATE_FWD_OPS);
+                 RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_OPS);
   else
-    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_MUL(0) "s_mov_b64 exec, -1\n\t" RELATE_FWD_ACC(0) RELATE_FWD_OPS);
+    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_MUL(0) "s_mov_b64 exec, -1\n\t" RELATE_FWD_ACC(c0, 0) RELATE_FWD_OPS);
 #undef RELATE_FWD_OPS
 }
 
@@ -303,47 +313,55 @@ __device__ __forceinline__ void fwd_batch(double& c0, double& c1, double& c2, do
   "s_andn2_b64 exec, %[skn], " RELATE_W(sn, i) "\n\tv_fma_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[rho], %[c1]\n\t"
 #define RELATE_BWD_ADD(i) \
   "s_orn2_b64 exec, " RELATE_W(sn, i) ", %[skn]\n\tv_add_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[aa]\n\t"
-#define RELATE_BWD_ALL(i) "v_add_f64 %[ca" #i "], %[ca" #i "], " RELATE_A(i) "\n\t"
-#define RELATE_BWD_MIS(i) \
-  "s_andn2_b64 exec, %[skc], " RELATE_W(sc, i) "\n\tv_add_f64 %[cm" #i "], %[cm" #i "], " RELATE_A(i) "\n\t"
+#define RELATE_BWD_ALL(c, i) "v_add_f64 %[" #c "], %[" #c "], " RELATE_A(i) "\n\t"
+#define RELATE_BWD_SET(c, i) "v_mov_b64 %[" #c "], " RELATE_A(i) "\n\t"
+#define RELATE_BWD_MIS(c, i) \
+  "s_andn2_b64 exec, %[skc], " RELATE_W(sc, i) "\n\tv_add_f64 %[" #c "], %[" #c "], " RELATE_A(i) "\n\t"
 
 struct BwdAcc {
-  double a0, a1, a2, a3;  // sums over all states
-  double m0, m1, m2, m3;  // sums over the states that mismatch at the current site
+  double a0, a1;  // sums over all states (initialised by the first batch of a site)
+  double m0, m1;  // sums over the states that mismatch at the current site (zeroed by the caller)
 };
 
 // backward sweep over NW words: update with the masks of the row handled one step earlier (s[SN..],
 // skn), sums with the masks of the current row (s[SC..], skc)
-template <int W0, int SN, int SC, int NW>
+template <int W0, int SN, int SC, int NW, bool FIRST>
 __device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, double aa, uint64_t skn, uint64_t skc)
 {
+  static_assert(!FIRST || NW >= 2, "the first batch initialises both accumulators");
 #define RELATE_BWD_OPS                                                                                         \
-  : [ca0] "+v"(c.a0), [ca1] "+v"(c.a1), [ca2] "+v"(c.a2), [ca3] "+v"(c.a3), [cm0] "+v"(c.m0), [cm1] "+v"(c.m1), \
-    [cm2] "+v"(c.m2), [cm3] "+v"(c.m3)                                                                         \
+  : [ca0] "+v"(c.a0), [ca1] "+v"(c.a1), [cm0] "+v"(c.m0), [cm1] "+v"(c.m1)                                     \
   : [rho] "v"(rho), [c1] "v"(c1), [aa] "v"(aa), [skn] "s"(skn), [skc] "s"(skc), [r] "n"(kA0 + 2 * W0),        \
     [sn] "n"(SN), [sc] "n"(SC)                                                                                 \
   : "scc"
-  if constexpr (NW == 4)
+  if constexpr (NW == 4 && FIRST)
     asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3)
                  RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2) RELATE_BWD_ADD(3)
                  "s_mov_b64 exec, -1\n\t"
-                 RELATE_BWD_ALL(0) RELATE_BWD_ALL(1) RELATE_BWD_ALL(2) RELATE_BWD_ALL(3)
-                 RELATE_BWD_MIS(0) RELATE_BWD_MIS(1) RELATE_BWD_MIS(2) RELATE_BWD_MIS(3)
+                 RELATE_BWD_SET(ca0, 0) RELATE_BWD_SET(ca1, 1) RELATE_BWD_ALL(ca0, 2) RELATE_BWD_ALL(ca1, 3)
+                 RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2) RELATE_BWD_MIS(cm1, 3)
+                 "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
+  else if constexpr (NW == 4)
+    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3)
+                 RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2) RELATE_BWD_ADD(3)
+                 "s_mov_b64 exec, -1\n\t"
+                 RELATE_BWD_ALL(ca0, 0) RELATE_BWD_ALL(ca1, 1) RELATE_BWD_ALL(ca0, 2) RELATE_BWD_ALL(ca1, 3)
+                 RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2) RELATE_BWD_MIS(cm1, 3)
                  "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
   else if constexpr (NW == 3)
     asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2)
                  RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2)
                  "s_mov_b64 exec, -1\n\t"
-                 RELATE_BWD_ALL(0) RELATE_BWD_ALL(1) RELATE_BWD_ALL(2)
-                 RELATE_BWD_MIS(0) RELATE_BWD_MIS(1) RELATE_BWD_MIS(2)
+                 RELATE_BWD_ALL(ca0, 0) RELATE_BWD_ALL(ca1, 1) RELATE_BWD_ALL(ca0, 2)
+                 RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2)
                  "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
   else if constexpr (NW == 2)
     asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_ADD(0) RELATE_BWD_ADD(1)
                  "s_mov_b64 exec, -1\n\t"
-                 RELATE_BWD_ALL(0) RELATE_BWD_ALL(1) RELATE_BWD_MIS(0) RELATE_BWD_MIS(1)
+                 RELATE_BWD_ALL(ca0, 0) RELATE_BWD_ALL(ca1, 1) RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1)
                  "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
   else
-    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_ADD(0) "s_mov_b64 exec, -1\n\t" RELATE_BWD_ALL(0) RELATE_BWD_MIS(0)
+    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_ADD(0) "s_mov_b64 exec, -1\n\t" RELATE_BWD_ALL(ca0, 0) RELATE_BWD_MIS(cm0, 0)
                  "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
 #undef RELATE_BWD_OPS
 }
@@ -355,44 +373,65 @@ __device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, doub
   "v_mov_b32_dpp v[%[t]+1], v[%[x]+1] " ctrl " row_mask:0xf bank_mask:0xf\n\t"           \
   "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"
 
-// Sum over the 64 lanes, the same bits in every lane: four exchange steps inside each 16-lane row,
-// then the four row sums through SGPRs, added as (r0 + r1) + (r2 + r3).
+// Sum over the 64 lanes of the value left in v[kX:kX+1], the same bits in every lane: four exchange
+// steps inside each 16-lane row, then the four row sums through SGPRs, added as (r0 + r1) + (r2 + r3).
+#define RELATE_WAVE_SUM_TAIL                                        \
+  RELATE_DPP_STEP("quad_perm:[1,0,3,2]")                            \
+  RELATE_DPP_STEP("quad_perm:[2,3,0,1]")                            \
+  RELATE_DPP_STEP("row_half_mirror")                                \
+  RELATE_DPP_STEP("row_mirror")                                     \
+  "s_nop 0\n\t"                                                     \
+  "v_readlane_b32 s[%[rl]+0], v[%[x]], 0\n\t"                       \
+  "v_readlane_b32 s[%[rl]+1], v[%[x]+1], 0\n\t"                     \
+  "v_readlane_b32 s[%[rl]+2], v[%[x]], 16\n\t"                      \
+  "v_readlane_b32 s[%[rl]+3], v[%[x]+1], 16\n\t"                    \
+  "v_readlane_b32 s[%[rl]+4], v[%[x]], 32\n\t"                      \
+  "v_readlane_b32 s[%[rl]+5], v[%[x]+1], 32\n\t"                    \
+  "v_readlane_b32 s[%[rl]+6], v[%[x]], 48\n\t"                      \
+  "v_readlane_b32 s[%[rl]+7], v[%[x]+1], 48\n\t"                    \
+  "s_nop 1\n\t"                                                     \
+  "v_mov_b64 v[%[t]:%[t]+1], s[%[rl]+2:%[rl]+3]\n\t"                \
+  "v_add_f64 v[%[t]:%[t]+1], s[%[rl]:%[rl]+1], v[%[t]:%[t]+1]\n\t"  \
+  "v_mov_b64 v[%[x]:%[x]+1], s[%[rl]+6:%[rl]+7]\n\t"                \
+  "v_add_f64 v[%[x]:%[x]+1], s[%[rl]+4:%[rl]+5], v[%[x]:%[x]+1]\n\t" \
+  "v_add_f64 %[out], v[%[t]:%[t]+1], v[%[x]:%[x]+1]"
+
+// wave sum of x
 __device__ __forceinline__ double wave_sum_regs(double x)
 {
   double out;
-  asm volatile(
-      "v_mov_b64 v[%[x]:%[x]+1], %[in]\n\t"
-      RELATE_DPP_STEP("quad_perm:[1,0,3,2]")
-      RELATE_DPP_STEP("quad_perm:[2,3,0,1]")
-      RELATE_DPP_STEP("row_half_mirror")
-      RELATE_DPP_STEP("row_mirror")
-      "s_nop 0\n\t"
-      "v_readlane_b32 s[%[rl]+0], v[%[x]], 0\n\t"
-      "v_readlane_b32 s[%[rl]+1], v[%[x]+1], 0\n\t"
-      "v_readlane_b32 s[%[rl]+2], v[%[x]], 16\n\t"
-      "v_readlane_b32 s[%[rl]+3], v[%[x]+1], 16\n\t"
-      "v_readlane_b32 s[%[rl]+4], v[%[x]], 32\n\t"
-      "v_readlane_b32 s[%[rl]+5], v[%[x]+1], 32\n\t"
-      "v_readlane_b32 s[%[rl]+6], v[%[x]], 48\n\t"
-      "v_readlane_b32 s[%[rl]+7], v[%[x]+1], 48\n\t"
-      "s_nop 1\n\t"
-      "v_mov_b64 v[%[t]:%[t]+1], s[%[rl]+2:%[rl]+3]\n\t"
-      "v_add_f64 v[%[t]:%[t]+1], s[%[rl]:%[rl]+1], v[%[t]:%[t]+1]\n\t"
-      "v_mov_b64 v[%[x]:%[x]+1], s[%[rl]+6:%[rl]+7]\n\t"
-      "v_add_f64 v[%[x]:%[x]+1], s[%[rl]+4:%[rl]+5], v[%[x]:%[x]+1]\n\t"
-      "v_add_f64 %[out], v[%[t]:%[t]+1], v[%[x]:%[x]+1]"
-      : [out] "=v"(out)
-      : [in] "v"(x), [x] "n"(kX), [t] "n"(kT), [rl] "n"(kRL));
+  asm volatile("v_mov_b64 v[%[x]:%[x]+1], %[in]\n\t" RELATE_WAVE_SUM_TAIL
+               : [out] "=v"(out)
+               : [in] "v"(x), [x] "n"(kX), [t] "n"(kT), [rl] "n"(kRL));
+  return out;
+}
+// wave sum of a + b
+__device__ __forceinline__ double wave_sum_regs(double a, double b)
+{
+  double out;
+  asm volatile("v_add_f64 v[%[x]:%[x]+1], %[a], %[b]\n\t" RELATE_WAVE_SUM_TAIL
+               : [out] "=v"(out)
+               : [a] "v"(a), [b] "v"(b), [x] "n"(kX), [t] "n"(kT), [rl] "n"(kRL));
+  return out;
+}
+// wave sum of wa * a + wb * b
+__device__ __forceinline__ double wave_sum_regs(double a, double wa, double b, double wb)
+{
+  double out;
+  asm volatile("v_mul_f64 v[%[x]:%[x]+1], %[b], %[wb]\n\t"
+               "v_fma_f64 v[%[x]:%[x]+1], %[a], %[wa], v[%[x]:%[x]+1]\n\t" RELATE_WAVE_SUM_TAIL
+               : [out] "=v"(out)
+               : [a] "v"(a), [wa] "v"(wa), [b] "v"(b), [wb] "v"(wb), [x] "n"(kX), [t] "n"(kT), [rl] "n"(kRL));
   return out;
 }
 
 // Sum over the G waves of the workgroup; `slot` alternates between two LDS rows so that one barrier
 // per call is enough (a row is rewritten two calls later, after every wave has passed the barrier of
 // the call in between).
-template <int G>
-__device__ __forceinline__ double block_sum_regs(double x, double (*red)[G], int& slot)
+template <int G, class... Parts>
+__device__ __forceinline__ double block_sum_regs(double (*red)[G], int& slot, Parts... parts)
 {
-  x = wave_sum_regs(x);
+  double x = wave_sum_regs(parts...);
   if constexpr (G == 1) {
     return x;
   } else {
@@ -538,7 +577,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       state_set<i>(v ? a : 0.0);
       acc += v ? a : 0.0;
     });
-    double S = block_sum_regs<G>(acc, red, slot);
+    double S = block_sum_regs<G>(red, slot, acc);
     double ls = 0.0;
     int wcur = 0;
     int stone_j = 0;  // list index at which the next alpha stone is due (window 0 starts at site 0)
@@ -571,12 +610,12 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     for (int j = 1; j < nd; j++) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
       const double rx = S * coef_j;
-      write_stateless<MPL>(-rx, z.selfm, z.selfidx, z.phm, z.phidx);
+      write_stateless<MPL>(S, coef_j, z.selfm, z.selfidx, z.phm, z.phidx);
       // scalars of site j+1 travel during this sweep: its successor in the list and the terms of the gap before it
       prefetch_site<true>();
       const uint64_t skm = edge_select(j, nd - 1, sk_last);
       ls += nx_j;
-      double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
+      double c0, c1;
       const uint64_t* rp_next = rows_w + (size_t)s_next * stride;
       static_for<0, NB>([&](auto ic) __attribute__((always_inline)) {
         constexpr int b = decltype(ic)::value;
@@ -588,11 +627,11 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         else sload4<nxt, 0>(rpn);
         const double rxl = rx, rhol = rho;
         const uint64_t skl = skm;
-        fwd_batch<4 * b, cur, (b + 1 < NB ? 4 : LASTW)>(c0, c1, c2, c3, rxl, rhol, skl);
+        fwd_batch<4 * b, cur, (b + 1 < NB ? 4 : LASTW), b == 0>(c0, c1, rxl, rhol, skl);
         swait();
       });
       if constexpr (NB & 1) scopy8<kBufA, kBufB>();
-      S = block_sum_regs<G>((c0 + c1) + (c2 + c3), red, slot);
+      S = block_sum_regs<G>(red, slot, c0, c1);
       int s_next2;
       fetched_site<true>(s_next2, coef_j, nx_j);
       if (out_of_range(S)) {
@@ -626,7 +665,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       state_set<i>(1.0);
       acc += v ? (m ? theta_d : ntheta_d) : 0.0;
     });
-    double B = block_sum_regs<G>(acc, red, slot);
+    double B = block_sum_regs<G>(red, slot, acc);
     int wcur = ka.p.W - 1;
     int stone_j = nd - 1;  // the last window ends at the last SNP
     // stones taken at the last SNP hold beta = 1 for every state, the target included (:427-432,:447-462)
@@ -662,13 +701,15 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       const double aa = rx * inv_nt;
       const double bb = rx * inv_t - aa;
       const double c1 = (bb + aa) * rho;
-      write_stateless<MPL>(-aa, z.selfm, z.selfidx, z.phm, z.phidx);
+      write_stateless<MPL>(rx, inv_nt, z.selfm, z.selfidx, z.phm, z.phidx);
       // scalars of the step to site j-1 travel during this sweep
       prefetch_site<false>();
       const uint64_t skn = edge_select(j, nd - 2, sk_last);
       const uint64_t skc = edge_select(j, 0, sk_first);
       ls += nx_j;
-      BwdAcc c = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      BwdAcc c;
+      c.m0 = 0.0;
+      c.m1 = 0.0;
       const uint64_t* rp_p = rows_w + (size_t)s_prev * stride;
       static_for<0, NB>([&](auto ic) __attribute__((always_inline)) {
         constexpr int b = decltype(ic)::value;
@@ -688,7 +729,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         }
         const double rhol = rho, c1l = c1, aal = aa;
         const uint64_t sknl = skn, skcl = skc;
-        bwd_batch<4 * b, curn, curc, (b + 1 < NB ? 4 : LASTW)>(c, rhol, c1l, aal, sknl, skcl);
+        bwd_batch<4 * b, curn, curc, (b + 1 < NB ? 4 : LASTW), b == 0>(c, rhol, c1l, aal, sknl, skcl);
         swait();
       });
       if constexpr (NB & 1) {
@@ -696,7 +737,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         scopy8<kBufC, kBufD>();
       }
       // B = (1-theta) * sum over matching states + theta * sum over mismatching states (:509-517)
-      B = block_sum_regs<G>(w_all * ((c.a0 + c.a1) + (c.a2 + c.a3)) + w_mis * ((c.m0 + c.m1) + (c.m2 + c.m3)), red, slot);
+      B = block_sum_regs<G>(red, slot, c.a0 + c.a1, w_all, c.m0 + c.m1, w_mis);
       int s_prev2;
       fetched_site<false>(s_prev2, coef_j, nx_j);
       if (out_of_range(B)) {

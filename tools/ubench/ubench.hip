@@ -8,8 +8,9 @@
 #define ITERS 4000
 
 template <int P>
-__global__ void k(double* out, const uint64_t* masks, int iters)
+__global__ void k(double* out, const uint64_t* masks, int iters, long long* cyc)
 {
+  const long long t_start = clock64();
   double a0 = threadIdx.x * 1e-3 + 1.0, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   double rx = 1e-9, rho = 0.999999;
   float f0 = a0, f1 = a1, f2 = a2, f3 = a3, f4 = a4, f5 = a5, f6 = a6, f7 = a7, fr = 1e-9f;
@@ -62,38 +63,143 @@ __global__ void k(double* out, const uint64_t* masks, int iters)
       asm volatile("v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n"
                    "v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n v_add_f64 %0, %0, %1\n"
                    : "+v"(a0) : "v"(rx));
+    } else if constexpr (P == 10) {  // 8 v_mov_b64
+      asm volatile("v_mov_b64 %0, %8\n v_mov_b64 %1, %8\n v_mov_b64 %2, %8\n v_mov_b64 %3, %8\n"
+                   "v_mov_b64 %4, %8\n v_mov_b64 %5, %8\n v_mov_b64 %6, %8\n v_mov_b64 %7, %8\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(rx));
+    } else if constexpr (P == 11) {  // backward batch of 4 words: 16 f64 + 14 salu
+      double c0 = 0, c1 = 0, m0 = 0, m1 = 0;
+      asm volatile(
+          "s_andn2_b64 exec, %12, %10\n v_fma_f64 %0, %0, %9, %8\n s_andn2_b64 exec, %12, %11\n v_fma_f64 %1, %1, %9, %8\n"
+          "s_andn2_b64 exec, %12, %10\n v_fma_f64 %2, %2, %9, %8\n s_andn2_b64 exec, %12, %11\n v_fma_f64 %3, %3, %9, %8\n"
+          "s_orn2_b64 exec, %10, %12\n v_add_f64 %0, %0, %8\n s_orn2_b64 exec, %11, %12\n v_add_f64 %1, %1, %8\n"
+          "s_orn2_b64 exec, %10, %12\n v_add_f64 %2, %2, %8\n s_orn2_b64 exec, %11, %12\n v_add_f64 %3, %3, %8\n"
+          "s_mov_b64 exec, -1\n v_add_f64 %4, %4, %0\n v_add_f64 %5, %5, %1\n v_add_f64 %4, %4, %2\n v_add_f64 %5, %5, %3\n"
+          "s_andn2_b64 exec, %12, %11\n v_add_f64 %6, %6, %0\n s_andn2_b64 exec, %12, %10\n v_add_f64 %7, %7, %1\n"
+          "s_andn2_b64 exec, %12, %11\n v_add_f64 %6, %6, %2\n s_andn2_b64 exec, %12, %10\n v_add_f64 %7, %7, %3\n"
+          "s_mov_b64 exec, -1\n"
+          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(m0), "+v"(m1)
+          : "v"(rx), "v"(rho), "s"(sm0), "s"(sm1), "s"(sm1) : "scc");
+      a4 += (c0 + c1 + m0 + m1) * 1e-30;
+    } else if constexpr (P == 12) {  // DPP reduction step x4: 8 dpp movs + 4 f64 adds, dependent, with the wait states
+      int lo = __double2loint(a0), hi = __double2hiint(a0), tl, th;
+      asm volatile(
+          "s_nop 1\n v_mov_b32_dpp %2, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n"
+          "s_nop 1\n v_mov_b32_dpp %2, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n"
+          "s_nop 1\n v_mov_b32_dpp %2, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n"
+          "s_nop 1\n v_mov_b32_dpp %2, %0 row_mirror row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %1 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3\n"
+          : "+v"(lo), "+v"(hi), "=&v"(tl), "=&v"(th));
+      a0 = __hiloint2double(hi, lo);
+    } else if constexpr (P == 13) {  // 8 SALU 64-bit logic ops on SGPRs (no exec)
+      uint64_t t0, t1;
+      asm volatile("s_andn2_b64 %0, %2, %3\n s_andn2_b64 %1, %3, %2\n s_andn2_b64 %0, %2, %3\n s_andn2_b64 %1, %3, %2\n"
+                   "s_andn2_b64 %0, %2, %3\n s_andn2_b64 %1, %3, %2\n s_andn2_b64 %0, %2, %3\n s_andn2_b64 %1, %3, %2\n"
+                   : "=&s"(t0), "=&s"(t1) : "s"(sm0), "s"(sm1) : "scc");
+      asm volatile("" ::"s"(t0), "s"(t1));
+    } else if constexpr (P == 14) {  // 8 exec writes
+      asm volatile("s_andn2_b64 exec, %0, %1\n s_andn2_b64 exec, %1, %0\n s_andn2_b64 exec, %0, %1\n s_andn2_b64 exec, %1, %0\n"
+                   "s_andn2_b64 exec, %0, %1\n s_andn2_b64 exec, %1, %0\n s_andn2_b64 exec, %0, %1\n s_mov_b64 exec, -1\n"
+                   :: "s"(sm0), "s"(sm1) : "scc");
+    } else if constexpr (P == 15) {  // 8 SALU 32-bit ops
+      uint32_t t0, t1;
+      asm volatile("s_add_u32 %0, %2, %3\n s_add_u32 %1, %3, %2\n s_add_u32 %0, %2, %3\n s_add_u32 %1, %3, %2\n"
+                   "s_add_u32 %0, %2, %3\n s_add_u32 %1, %3, %2\n s_add_u32 %0, %2, %3\n s_add_u32 %1, %3, %2\n"
+                   : "=&s"(t0), "=&s"(t1) : "s"((uint32_t)sm0), "s"((uint32_t)sm1) : "scc");
+      asm volatile("" ::"s"(t0), "s"(t1));
+    } else if constexpr (P == 16) {  // backward batch, fewer exec writes: unmasked add, masked fma (16 f64 + 10 s)
+      double c0 = 0, c1 = 0, m0 = 0, m1 = 0;
+      asm volatile(
+          "v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+          "s_andn2_b64 exec, %12, %10\n v_fma_f64 %0, %0, %9, %8\n s_andn2_b64 exec, %12, %11\n v_fma_f64 %1, %1, %9, %8\n"
+          "s_andn2_b64 exec, %12, %10\n v_fma_f64 %2, %2, %9, %8\n s_andn2_b64 exec, %12, %11\n v_fma_f64 %3, %3, %9, %8\n"
+          "s_mov_b64 exec, -1\n v_add_f64 %4, %4, %0\n v_add_f64 %5, %5, %1\n v_add_f64 %4, %4, %2\n v_add_f64 %5, %5, %3\n"
+          "s_andn2_b64 exec, %12, %11\n v_add_f64 %6, %6, %0\n s_andn2_b64 exec, %12, %10\n v_add_f64 %7, %7, %1\n"
+          "s_andn2_b64 exec, %12, %11\n v_add_f64 %6, %6, %2\n s_andn2_b64 exec, %12, %10\n v_add_f64 %7, %7, %3\n"
+          "s_mov_b64 exec, -1\n"
+          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(m0), "+v"(m1)
+          : "v"(rx), "v"(rho), "s"(sm0), "s"(sm1), "s"(sm1) : "scc");
+      a4 += (c0 + c1 + m0 + m1) * 1e-30;
+    } else if constexpr (P == 17) {  // backward mix, no masks (16 f64)
+      double c0 = 0, c1 = 0, m0 = 0, m1 = 0;
+      asm volatile(
+          "v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+          "v_fma_f64 %0, %0, %9, %8\n v_fma_f64 %1, %1, %9, %8\n"
+          "v_fma_f64 %2, %2, %9, %8\n v_fma_f64 %3, %3, %9, %8\n"
+          "v_add_f64 %4, %4, %0\n v_add_f64 %5, %5, %1\n v_add_f64 %4, %4, %2\n v_add_f64 %5, %5, %3\n"
+          "v_add_f64 %6, %6, %0\n v_add_f64 %7, %7, %1\n"
+          "v_add_f64 %6, %6, %2\n v_add_f64 %7, %7, %3\n"
+          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(m0), "+v"(m1)
+          : "v"(rx), "v"(rho), "s"(sm0), "s"(sm1), "s"(sm1) : "scc");
+      a4 += (c0 + c1 + m0 + m1) * 1e-30;
+    } else if constexpr (P == 18) {  // backward mix, masks on fma only (16 f64 + 5 s)
+      double c0 = 0, c1 = 0, m0 = 0, m1 = 0;
+      asm volatile(
+          "v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+          "s_andn2_b64 exec, %12, %10\n v_fma_f64 %0, %0, %9, %8\n s_andn2_b64 exec, %12, %11\n v_fma_f64 %1, %1, %9, %8\n"
+          "s_andn2_b64 exec, %12, %10\n v_fma_f64 %2, %2, %9, %8\n s_andn2_b64 exec, %12, %11\n v_fma_f64 %3, %3, %9, %8\n"
+          "s_mov_b64 exec, -1\n"
+          "v_add_f64 %4, %4, %0\n v_add_f64 %5, %5, %1\n v_add_f64 %4, %4, %2\n v_add_f64 %5, %5, %3\n"
+          "v_add_f64 %6, %6, %0\n v_add_f64 %7, %7, %1\n"
+          "v_add_f64 %6, %6, %2\n v_add_f64 %7, %7, %3\n"
+          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(m0), "+v"(m1)
+          : "v"(rx), "v"(rho), "s"(sm0), "s"(sm1), "s"(sm1) : "scc");
+      a4 += (c0 + c1 + m0 + m1) * 1e-30;
+    } else if constexpr (P == 19) {  // backward mix, masks on masked sums only (16 f64 + 5 s)
+      double c0 = 0, c1 = 0, m0 = 0, m1 = 0;
+      asm volatile(
+          "v_add_f64 %0, %0, %8\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+          "v_fma_f64 %0, %0, %9, %8\n v_fma_f64 %1, %1, %9, %8\n"
+          "v_fma_f64 %2, %2, %9, %8\n v_fma_f64 %3, %3, %9, %8\n"
+          "v_add_f64 %4, %4, %0\n v_add_f64 %5, %5, %1\n v_add_f64 %4, %4, %2\n v_add_f64 %5, %5, %3\n"
+          "s_andn2_b64 exec, %12, %11\n v_add_f64 %6, %6, %0\n s_andn2_b64 exec, %12, %10\n v_add_f64 %7, %7, %1\n"
+          "s_andn2_b64 exec, %12, %11\n v_add_f64 %6, %6, %2\n s_andn2_b64 exec, %12, %10\n v_add_f64 %7, %7, %3\n"
+          "s_mov_b64 exec, -1\n"
+          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(m0), "+v"(m1)
+          : "v"(rx), "v"(rho), "s"(sm0), "s"(sm1), "s"(sm1) : "scc");
+      a4 += (c0 + c1 + m0 + m1) * 1e-30;
     } else if constexpr (P == 9) {  // 8 v_cndmask_b32 with SGPR mask
       asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
                    "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n"
                    : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(fr), "s"(sm0));
     }
   }
+  if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = clock64() - t_start;
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;
 }
 
 template <int P>
 void run(const char* name, int instrs, double* d_out, uint64_t* d_masks)
 {
-  for (int waves : {1, 2, 4}) {
+  static long long* d_cyc = nullptr;
+  if (!d_cyc) hipMalloc(&d_cyc, sizeof(long long) * 512 * 16);
+  for (int waves : {1, 2, 4, 8}) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    dim3 grid(256), block(256 * waves);
-    hipLaunchKernelGGL(k<P>, grid, block, 0, 0, d_out, d_masks, 100);
+    // one block per CU up to 4 waves per SIMD; two blocks of 1024 threads per CU for 8
+    dim3 grid(waves == 8 ? 512 : 256), block(waves == 8 ? 1024 : 256 * waves);
+    hipLaunchKernelGGL(k<P>, grid, block, 0, 0, d_out, d_masks, 100, d_cyc);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k<P>, grid, block, 0, 0, d_out, d_masks, ITERS);
+    hipLaunchKernelGGL(k<P>, grid, block, 0, 0, d_out, d_masks, ITERS, d_cyc);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
+    const int nw = grid.x * block.x / 64;
+    std::vector<long long> h(nw);
+    hipMemcpy(h.data(), d_cyc, sizeof(long long) * nw, hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (long long v : h) mean += (double)v;
+    mean /= nw;
     double cyc = ms * 1e-3 * 2.4e9 / ((double)ITERS * instrs * waves);
-    printf("%-28s waves/SIMD %d  %8.3f ms  %6.2f cycles (at 2.4 GHz) per instr per SIMD\n", name, waves, ms, cyc);
+    printf("%-28s waves/SIMD %d  %8.3f ms  %6.2f cycles (at 2.4 GHz) per instr per SIMD; clock64 ticks per instr per SIMD %6.2f (ticks/ms %.0f)\n",
+           name, waves, ms, cyc, mean / ((double)ITERS * instrs * waves), mean / ms);
   }
 }
 
 int main()
 {
   double* d_out; uint64_t* d_masks;
-  hipMalloc(&d_out, 256 * 1024 * 8);
+  hipMalloc(&d_out, 512 * 1024 * 8);
   hipMalloc(&d_masks, 16);
   uint64_t h[2] = {0x5555aaaa3333ccccull, 0x0f0ff0f012345678ull};
   hipMemcpy(d_masks, h, 16, hipMemcpyHostToDevice);
@@ -106,5 +212,15 @@ int main()
   run<6>("same, no exec toggles (24)", 24, d_out, d_masks);
   run<7>("v_readlane_b32 x8", 8, d_out, d_masks);
   run<9>("v_cndmask_b32 sgpr mask x8", 8, d_out, d_masks);
+  run<10>("v_mov_b64 x8", 8, d_out, d_masks);
+  run<11>("bwd batch (16 f64+14 s)", 30, d_out, d_masks);
+  run<12>("dpp reduce (8 dpp+8 f32)", 16, d_out, d_masks);
+  run<13>("s_andn2_b64 sgpr x8", 8, d_out, d_masks);
+  run<14>("exec writes x8", 8, d_out, d_masks);
+  run<15>("s_add_u32 x8", 8, d_out, d_masks);
+  run<16>("bwd batch B (16 f64+10 s)", 26, d_out, d_masks);
+  run<17>("bwd mix no masks (16)", 16, d_out, d_masks);
+  run<18>("bwd mix fma masks (16+5)", 21, d_out, d_masks);
+  run<19>("bwd mix sum masks (16+5)", 21, d_out, d_masks);
   return 0;
 }
