@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--waves", type=int, default=0, help="waves per target (0 = automatic)")
-    ap.add_argument("--variant", type=int, default=2, help="recursion kernel: 2 register-resident, 1 hand-scheduled, 0 plain")
+    ap.add_argument("--variant", type=int, default=1, help="recursion kernel: 1 register-resident, 0 plain HIP cross-check")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--N", type=int, default=0, help="override the number of haplotypes (experiments)")
     ap.add_argument("--L", type=int, default=0, help="override the number of SNPs (experiments)")
@@ -178,7 +178,7 @@ def main():
                        "kernel_geometry": geo, "parallelism": f"{world} independent chunk(s), one per GPU"},
             "actual_state_updates_per_s": u_actual * world / dt * args.steps,
             "stage_ms": kern,
-            "roofline": {"bound": "valu_fp64", "kernel": "paint_kernel_x (forward+backward recursion)",
+            "roofline": {"bound": "valu_fp64", "kernel": "paint_kernel_r (forward / backward recursion, one workgroup per pass)",
                          "achieved": f_alg / t_paint / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": f_alg / t_paint / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic},
             "roofline_hbm": {"bound": "hbm", "achieved": b_alg / t_paint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -103,8 +103,8 @@ typedef struct relate_plan relate_plan;
 
 int relate_plan_create(int device, relate_plan** out);
 void relate_plan_destroy(relate_plan* p);
-/* Kernel choice: variant 1 = hand-scheduled (default), 0 = plain HIP cross-check (small N only);
- * waves_per_target 0 = automatic, else 1/2/4/8. */
+/* Kernel choice: variant 1 = register-resident recursion (default), 0 = plain HIP cross-check (N <= 4096);
+ * waves_per_target 0 = automatic, else 1/2/4/8.  Call relate_plan_prepare again after changing it. */
 int relate_plan_configure(relate_plan* p, int variant, int waves_per_target);
 
 /* Packs Data::sequence ('0'/'1' bytes, device pointer d_seq, L x N) into bit rows and their transpose

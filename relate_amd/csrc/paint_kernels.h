@@ -39,7 +39,7 @@ struct PaintArgs {
   const int32_t* dk;       // flat derived-site lists
   const double* coef;      // flat r_prob/((1-r_prob)(N-1)) per derived site
   const double* nx;        // flat nor_x_theta per derived site
-  const SiteRec* rec;      // the same interleaved (variant 2 reads this instead of coef / nx)
+  const SiteRec* rec;      // the same interleaved (the register-resident kernel reads this instead of coef / nx)
   const int64_t* off;      // [K] start of target t's lists
   const int32_t* nd;       // [K] number of derived sites
   const int32_t* bbj;      // [K][W] index into the list where window w's alpha stone is taken
@@ -75,7 +75,7 @@ hipError_t launch_site_terms(const int32_t* d_dk, const int64_t* d_off, const in
                              SiteRec* d_rec, hipStream_t st);
 hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int W,
                                 const int32_t* d_wb, int32_t* d_bbj, int32_t* d_bej, hipStream_t st);
-// variant: 0 = plain HIP recursion, 1 = exec-masked inline-asm recursion, 2 = register-resident recursion
+// variant: 0 = plain HIP recursion (cross-check, N <= 4096), 1 = register-resident recursion
 hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStream_t st);
 hipError_t launch_fast_log(const float* d_in, float* d_out, int n, hipStream_t st);
 

@@ -392,23 +392,22 @@ hipError_t launch_plain_t(const PaintArgs& a, hipStream_t st)
 int row_stride_words(int N) { return ((N + 63) / 64 + 7) / 8 * 8; }
 int col_stride_words(int L) { return (L + 63) / 64; }
 
-// Plain-HIP kernels exist for a few small geometries only (cross-check of the hand-scheduled ones).
+// Plain-HIP kernels exist for a few small geometries only (cross-check of the register-resident ones).
 static const int kMplPlain[] = {1, 4, 16};
-static const int kMplHand[] = {8, 16, 24, 32, 40, 48, 64, 80};
 static const int kMplRegs[] = {4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80};
 
 PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
 {
   const int M = (N + 63) / 64;
-  const int* tab = variant == 0 ? kMplPlain : variant == 1 ? kMplHand : kMplRegs;
-  const int ntab = variant == 0 ? 3 : variant == 1 ? 8 : 15;
+  const int* tab = variant == 0 ? kMplPlain : kMplRegs;
+  const int ntab = variant == 0 ? 3 : 15;
   const int maxG = variant == 0 ? 4 : 8;
   const int mpl_max = tab[ntab - 1];
   int G = 1;
   if (prefer_waves == 2 || prefer_waves == 4 || prefer_waves == 8) G = prefer_waves;
   // The register-resident kernel is fastest with at most 32 states per lane (120 VGPRs: four waves per
   // SIMD); measured on MI355X: N=2000 best with 1 wave per target, N=5008 with 4.
-  if (variant == 2 && prefer_waves == 0)
+  if (variant == 1 && prefer_waves == 0)
     while (G < maxG && (M + G - 1) / G > 32) G *= 2;
   if (G > maxG) G = maxG;
   while (G < maxG && (M + G - 1) / G > mpl_max) G *= 2;
@@ -421,7 +420,7 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
     }
   if (variant != 0 && G == 8 && MPL == 80) MPL = 0;  // stone staging would exceed the LDS of a CU
   // the register-resident kernel reads G*MPL words of every row and needs the padding bits of all of them
-  if (variant == 2 && MPL > 0 && G * MPL > row_stride_words(N)) {
+  if (variant == 1 && MPL > 0 && G * MPL > row_stride_words(N)) {
     if (G > 1) return choose_geometry(N, G / 2, variant);
     MPL = 0;
   }
@@ -494,11 +493,6 @@ hipError_t launch_fast_log(const float* d_in, float* d_out, int n, hipStream_t s
   return hipGetLastError();
 }
 
-// defined in paint_hand_g*.hip
-hipError_t launch_paint_hand_g1(const PaintArgs& a, int MPL, hipStream_t st);
-hipError_t launch_paint_hand_g2(const PaintArgs& a, int MPL, hipStream_t st);
-hipError_t launch_paint_hand_g4(const PaintArgs& a, int MPL, hipStream_t st);
-hipError_t launch_paint_hand_g8(const PaintArgs& a, int MPL, hipStream_t st);
 // defined in paint_regs_g*.hip
 hipError_t launch_paint_regs_g1(const PaintArgs& a, int MPL, hipStream_t st);
 hipError_t launch_paint_regs_g2(const PaintArgs& a, int MPL, hipStream_t st);
@@ -519,21 +513,13 @@ hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStr
     RELATE_PLAIN_CASE(1, 4) RELATE_PLAIN_CASE(4, 4) RELATE_PLAIN_CASE(16, 4)
     return hipErrorInvalidValue;
   }
-  if (variant == 2) {
-    if (g.G * g.MPL > a.row_stride || !a.rec) return hipErrorInvalidValue;
-    switch (g.G) {
-      case 1: return launch_paint_regs_g1(a, g.MPL, st);
-      case 2: return launch_paint_regs_g2(a, g.MPL, st);
-      case 4: return launch_paint_regs_g4(a, g.MPL, st);
-      case 8: return launch_paint_regs_g8(a, g.MPL, st);
-      default: return hipErrorInvalidValue;
-    }
-  }
+  if (variant != 1) return hipErrorInvalidValue;
+  if (g.G * g.MPL > a.row_stride || !a.rec) return hipErrorInvalidValue;
   switch (g.G) {
-    case 1: return launch_paint_hand_g1(a, g.MPL, st);
-    case 2: return launch_paint_hand_g2(a, g.MPL, st);
-    case 4: return launch_paint_hand_g4(a, g.MPL, st);
-    case 8: return launch_paint_hand_g8(a, g.MPL, st);
+    case 1: return launch_paint_regs_g1(a, g.MPL, st);
+    case 2: return launch_paint_regs_g2(a, g.MPL, st);
+    case 4: return launch_paint_regs_g4(a, g.MPL, st);
+    case 8: return launch_paint_regs_g8(a, g.MPL, st);
     default: return hipErrorInvalidValue;
   }
 }

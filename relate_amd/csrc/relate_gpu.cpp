@@ -1,5 +1,5 @@
 // Host side of librelate_gpu.so: the C ABI of include/relate_gpu.h over the
-// gfx950 kernels (paint_kernels.hip, paint_hand_g*.hip).  Mirrors, for the
+// gfx950 kernels (paint_kernels.hip, paint_regs_g*.hip).  Mirrors, for the
 // painting path only, what pipeline/Paint.cpp and src/data.cpp do on the host:
 // reading the chunk files, the loop over targets, and the record files.
 //
@@ -115,7 +115,7 @@ int check_windows(int L, int W, const int32_t* wb)
 struct relate_plan {
   int device = 0;
   hipStream_t own_stream = nullptr;
-  int variant = 2, prefer_waves = 0;
+  int variant = 1, prefer_waves = 0;
   // chunk
   int N = 0, L = 0, W = 0;
   int row_stride = 0, col_stride = 0;
@@ -216,7 +216,7 @@ void relate_plan_destroy(relate_plan* p)
 int relate_plan_configure(relate_plan* p, int variant, int waves_per_target)
 {
   if (!p) return fail(RELATE_EINVAL, "null plan");
-  if (variant < 0 || variant > 2) return fail(RELATE_EINVAL, "variant must be 0, 1 or 2");
+  if (variant != 0 && variant != 1) return fail(RELATE_EINVAL, "variant must be 0 or 1");
   if (waves_per_target != 0 && waves_per_target != 1 && waves_per_target != 2 && waves_per_target != 4 &&
       waves_per_target != 8)
     return fail(RELATE_EINVAL, "waves_per_target must be 0, 1, 2, 4 or 8");
@@ -368,7 +368,7 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   if (int rc = p->off.reserve(sizeof(int64_t) * (size_t)K)) return rc;
   if (int rc = p->order.reserve(sizeof(int32_t) * (size_t)K)) return rc;
   if (int rc = p->dk.reserve(sizeof(int32_t) * (size_t)total)) return rc;
-  const bool records = p->variant == 2;  // the register-resident kernel reads interleaved site records
+  const bool records = p->variant == 1;  // the register-resident kernel reads interleaved site records
   if (records) {
     if (int rc = p->rec.reserve(sizeof(relate::SiteRec) * (size_t)total)) return rc;
   } else {
@@ -427,7 +427,7 @@ int relate_plan_paint(relate_plan* p, void* d_out, void* stream)
   a.trace = nullptr;
   // Diagnostics: RELATE_TRACE=<file> makes the register-resident kernel record, per workgroup, where it
   // ran and when it started and ended (4 x u64: hardware id, start, end in 100 MHz ticks, pass | nd << 8).
-  const char* trace_path = p->variant == 2 ? std::getenv("RELATE_TRACE") : nullptr;
+  const char* trace_path = p->variant == 1 ? std::getenv("RELATE_TRACE") : nullptr;
   const size_t trace_words = (size_t)8 * p->K;
   if (trace_path && *trace_path) {
     if (int rc = p->trace.reserve(sizeof(uint64_t) * trace_words)) return rc;

@@ -60,6 +60,7 @@ def gpu_paint(seq, r, tp, td, wb, variant=1, waves=0, k_begin=0, k_end=None):
     plan.load_host(seq, r, wb)
     plan.prepare(tp, td, k_begin, k_end)
     out = torch.zeros(plan.out_bytes(), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()  # the fill runs on torch's stream, the kernels below on the plan's own
     plan.paint(out.data_ptr())
     plan.timings()  # waits for the kernel
     res = out.cpu().numpy().reshape(plan.W, k_end - k_begin, ra.record_bytes(N))
@@ -83,14 +84,14 @@ def test_fast_log_bit_exact():
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
-@pytest.mark.parametrize("variant,waves", [(2, 0), (2, 2), (2, 4), (2, 8), (1, 0), (1, 2), (1, 4), (0, 0), (0, 2)])
+@pytest.mark.parametrize("variant,waves", [(1, 0), (1, 2), (1, 4), (1, 8), (0, 0), (0, 2)])
 def test_golden_vectors(name, variant, waves):
     g = load_golden(name)
     got = gpu_paint(g["seq"], g["r"], g["theta_painter"], g["theta_data"], g["wb"], variant, waves)
     frac = compare_records(got, g["stones"], g["N"], f"{name} v{variant} g{waves}")
-    # variants 0 and 1 round every operation as the reference does and differ only in the order of the
-    # sums; variant 2 also fuses / reassociates the backward update, so more last bits differ
-    assert frac < (1e-3 if variant < 2 else 0.2), f"{frac:.2e} of the floats are not bit-identical to the reference"
+    # variant 0 rounds every operation as the reference does and differs only in the order of the sums;
+    # variant 1 also fuses / reassociates the backward update, so more last bits differ
+    assert frac < (1e-3 if variant == 0 else 0.2), f"{frac:.2e} of the floats are not bit-identical to the reference"
 
 
 def test_entry_point_host_buffers_matches_golden():
@@ -112,13 +113,12 @@ def test_entry_point_host_buffers_matches_golden():
     (2048, 600, 2, 26, "flat", 0.001, 0.001, 0),     # N a multiple of 64: no partial word
     (2, 50, 2, 27, "flat", 0.01, 0.01, 0),           # smallest N
 ])
-@pytest.mark.parametrize("variant", [2, 1])
-def test_against_oracle(N, L, W, seed, mode, tp, td, waves, variant):
+def test_against_oracle(N, L, W, seed, mode, tp, td, waves):
     seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=seed, r_mode=mode, empty_window=(W >= 3))
     want = ol.oracle().paint_stones(seq, r, tp, td, wb)
-    got = gpu_paint(seq, r, tp, td, wb, variant, waves)
-    frac = compare_records(got, want, N, f"N={N} L={L} v{variant}")
-    assert frac < (1e-3 if variant < 2 else 0.2)
+    got = gpu_paint(seq, r, tp, td, wb, 1, waves)
+    frac = compare_records(got, want, N, f"N={N} L={L}")
+    assert frac < 0.2
 
 
 def test_full_size_sampled_targets_and_structure():
