@@ -136,8 +136,24 @@ int relate_plan_prepare(relate_plan* p, double theta_painter, double theta_data,
 /* Forward + backward recursion of the prepared targets (src/fast_painting.cpp:214-599); writes
  * num_windows x K records into d_out (device pointer, relate_record_bytes(N)*K*num_windows bytes). */
 int relate_plan_paint(relate_plan* p, void* d_out, void* stream);
+/* Re-painting of one window from its stepping stones for the prepared targets:
+ *   void FastPainting::RePaintSection(const Data&, CollapsedMatrix<float>& topology, std::vector<float>& logscales,
+ *        CollapsedMatrix<float>& alpha_begin, CollapsedMatrix<float>& beta_end, int boundarySNP_begin,
+ *        int boundarySNP_end, float logscale_alpha, float logscale_beta, const int k) const
+ * (src/fast_painting.cpp:654-1126), called for k = 0..N-1 by DistanceMeasure::GetTopologyWithRepaint
+ * (src/anc_builder.cpp:53-110).  d_stones: the records of window `window` of the prepared targets as
+ * relate_plan_paint wrote them (slab `window` of its output, K x relate_record_bytes(N) bytes, device
+ * pointer).  Target t gets rows row_offsets[t] .. row_offsets[t+1]-1 (one per site of its section: the stone
+ * sites and every site in between at which it carries the derived allele); row i of d_topology starts at
+ * float index i*pitch and holds N floats alpha*beta (pitch >= N, the rest of the row is zero), d_logscales[i]
+ * is its logscale.  The painter's theta is the one given to relate_plan_prepare as theta_painter; the
+ * reference builds this painter from Data, i.e. with theta_painter == theta_data.
+ * relate_plan_repaint_layout only computes the layout (row_offsets: K+1 entries, may be NULL). */
+int relate_plan_repaint_layout(relate_plan* p, int window, int64_t* total_rows, int* pitch, int64_t* row_offsets);
+int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* d_topology, void* d_logscales,
+                        void* stream);
 /* Milliseconds of the last pack / prepare / paint, from HIP events on the stream they ran on
- * (blocks until the paint has finished). */
+ * (blocks until the paint has finished); after relate_plan_repaint, ms_paint is the time of its two launches. */
 int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float* ms_paint);
 /* Geometry the recursion kernel was launched with. */
 int relate_plan_geometry(const relate_plan* p, int* waves_per_target, int* states_per_lane);

@@ -73,10 +73,38 @@ hipError_t launch_fill_sites(const uint64_t* d_cols, int col_stride, int L, int 
 hipError_t launch_site_terms(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int max_nd,
                              const double* d_r, int L, const PaintConsts& c, double* d_coef, double* d_nx,
                              SiteRec* d_rec, hipStream_t st);
+// Gap terms of the last site of window w's section of every target: r[last] alone (src/fast_painting.cpp:737-750).
+hipError_t launch_section_last_terms(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_bej, int K, int W, int w,
+                                     const double* d_r, const PaintConsts& c, double* d_coef, double* d_nx,
+                                     hipStream_t st);
 hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int W,
                                 const int32_t* d_wb, int32_t* d_bbj, int32_t* d_bej, hipStream_t st);
 // variant: 0 = plain HIP recursion (cross-check, N <= 4096), 1 = register-resident recursion
 hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStream_t st);
 hipError_t launch_fast_log(const float* d_in, float* d_out, int n, hipStream_t st);
+
+// Re-painting of one window from its stones (register-resident kernels, repaint_regs.hpp).
+struct RepaintLaunch {
+  const uint64_t* rows;
+  int row_stride;
+  const int32_t* dk;
+  const SiteRec* rec;
+  const int64_t* off;
+  const int32_t* nd;
+  const int32_t* bbj;
+  const int32_t* bej;
+  const int32_t* order;
+  const uint8_t* stones;    // [K] records of window w
+  const int64_t* row_off;   // [K] first row of each target
+  const double* last_coef;  // [K]
+  const double* last_nx;
+  double* scratch;          // [rows][pitch]
+  float* topology;          // [rows][pitch]
+  float* logscales;         // [rows]
+  int w, pitch;
+  int N, L, W, k_begin, K;
+  PaintConsts c;
+};
+hipError_t launch_repaint(const RepaintLaunch& a, PaintGeometry g, hipStream_t st);
 
 }  // namespace relate

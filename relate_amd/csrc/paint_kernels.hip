@@ -174,6 +174,25 @@ __global__ void __launch_bounds__(256) site_terms_kernel(const int32_t* __restri
   }
 }
 
+__global__ void section_last_terms_kernel(const int32_t* __restrict__ dk, const int64_t* __restrict__ off,
+                                          const int32_t* __restrict__ bej, int K, int W, int w,
+                                          const double* __restrict__ r, double log_ntheta, double log_small, double Nm1,
+                                          double* __restrict__ coef, double* __restrict__ nx)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= K) return;
+  const int s = dk[off[t] + bej[(long long)t * W + w]];
+  const double rsum = r[s];
+  double nxv = -rsum + log_ntheta;
+  double rp = 1.0 - exp(-rsum);
+  if (rp > 0.99) {
+    rp = 0.99;
+    nxv = log_small + log_ntheta;
+  }
+  coef[t] = rp / ((1.0 - rp) * Nm1);
+  nx[t] = nxv;
+}
+
 // Window bookkeeping (src/fast_painting.cpp:33-45,:73-82,:111-120,:163-166) in
 // closed form: for the edge e = wb[w] (w >= 1), q = first derived site >= e
 // closes window w-1 and its predecessor opens window w.
@@ -478,6 +497,15 @@ hipError_t launch_site_terms(const int32_t* d_dk, const int64_t* d_off, const in
   return hipGetLastError();
 }
 
+hipError_t launch_section_last_terms(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_bej, int K, int W, int w,
+                                     const double* d_r, const PaintConsts& c, double* d_coef, double* d_nx,
+                                     hipStream_t st)
+{
+  hipLaunchKernelGGL(section_last_terms_kernel, dim3((K + 255) / 256), dim3(256), 0, st, d_dk, d_off, d_bej, K, W, w, d_r,
+                     c.log_ntheta, c.log_small, c.Nm1, d_coef, d_nx);
+  return hipGetLastError();
+}
+
 hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int W,
                                 const int32_t* d_wb, int32_t* d_bbj, int32_t* d_bej, hipStream_t st)
 {
@@ -520,6 +548,25 @@ hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStr
     case 2: return launch_paint_regs_g2(a, g.MPL, st);
     case 4: return launch_paint_regs_g4(a, g.MPL, st);
     case 8: return launch_paint_regs_g8(a, g.MPL, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// defined in paint_regs_g*.hip
+hipError_t launch_repaint_regs_g1(const RepaintLaunch& a, int MPL, hipStream_t st);
+hipError_t launch_repaint_regs_g2(const RepaintLaunch& a, int MPL, hipStream_t st);
+hipError_t launch_repaint_regs_g4(const RepaintLaunch& a, int MPL, hipStream_t st);
+hipError_t launch_repaint_regs_g8(const RepaintLaunch& a, int MPL, hipStream_t st);
+
+hipError_t launch_repaint(const RepaintLaunch& a, PaintGeometry g, hipStream_t st)
+{
+  if (g.MPL <= 0 || (long long)g.G * g.MPL * 64 < a.N || g.G * g.MPL > a.row_stride) return hipErrorInvalidValue;
+  if (a.pitch != g.G * g.MPL * 64 || a.K < 1 || a.w < 0 || a.w >= a.W || !a.rec) return hipErrorInvalidValue;
+  switch (g.G) {
+    case 1: return launch_repaint_regs_g1(a, g.MPL, st);
+    case 2: return launch_repaint_regs_g2(a, g.MPL, st);
+    case 4: return launch_repaint_regs_g4(a, g.MPL, st);
+    case 8: return launch_repaint_regs_g8(a, g.MPL, st);
     default: return hipErrorInvalidValue;
   }
 }

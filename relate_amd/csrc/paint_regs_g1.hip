@@ -1,6 +1,10 @@
-// Instantiates the register-resident recursion kernel for 1 wave(s) per target.
-#include "paint_regs.hpp"
+// Instantiates the register-resident recursion and re-painting kernels for 1 wave(s) per target.
+#include "repaint_regs.hpp"
 
 namespace relate {
 hipError_t launch_paint_regs_g1(const PaintArgs& a, int MPL, hipStream_t st) { return regs::launch_regs_g<1>(a, MPL, st); }
+hipError_t launch_repaint_regs_g1(const RepaintLaunch& a, int MPL, hipStream_t st)
+{
+  return regs::launch_repaint_g<1>(a, MPL, st);
+}
 }  // namespace relate

@@ -1,6 +1,10 @@
-// Instantiates the register-resident recursion kernel for 8 wave(s) per target.
-#include "paint_regs.hpp"
+// Instantiates the register-resident recursion and re-painting kernels for 8 wave(s) per target.
+#include "repaint_regs.hpp"
 
 namespace relate {
 hipError_t launch_paint_regs_g8(const PaintArgs& a, int MPL, hipStream_t st) { return regs::launch_regs_g<8>(a, MPL, st); }
+hipError_t launch_repaint_regs_g8(const RepaintLaunch& a, int MPL, hipStream_t st)
+{
+  return regs::launch_repaint_g<8>(a, MPL, st);
+}
 }  // namespace relate

@@ -131,6 +131,9 @@ struct relate_plan {
   double theta_p = 0, theta_d = 0;
   DevBuf nd, off, dk, coef, nx, bbj, bej, order;
   DevBuf trace, rec;
+  // re-painting
+  std::vector<int32_t> h_bbj, h_bej;  // host copies of the stone indices, [K][W]
+  DevBuf row_off, last_coef, last_nx, scratch;
   std::vector<int32_t> h_nd;
   std::vector<int64_t> h_off;
   int64_t sum_nd = 0;
@@ -205,7 +208,7 @@ void relate_plan_destroy(relate_plan* p)
   if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
   if (!p->packed_borrowed) p->packed.release();
   for (DevBuf* b : {&p->seq_own, &p->r_own, &p->wb_dev, &p->nd, &p->off, &p->dk, &p->coef, &p->nx, &p->bbj, &p->bej,
-                    &p->order, &p->trace, &p->rec})
+                    &p->order, &p->trace, &p->rec, &p->row_off, &p->last_coef, &p->last_nx, &p->scratch})
     b->release();
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
@@ -387,6 +390,10 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   HIP_TRY(relate::launch_window_stones(p->dk.as<int32_t>(), p->off.as<int64_t>(), p->nd.as<int32_t>(), K, W,
                                        p->wb_dev.as<int32_t>(), p->bbj.as<int32_t>(), p->bej.as<int32_t>(), st));
   HIP_TRY(hipEventRecord(p->ev[3], st));
+  p->h_bbj.resize((size_t)K * W);
+  p->h_bej.resize((size_t)K * W);
+  HIP_TRY(hipMemcpyAsync(p->h_bbj.data(), p->bbj.p, sizeof(int32_t) * (size_t)K * W, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(p->h_bej.data(), p->bej.p, sizeof(int32_t) * (size_t)K * W, hipMemcpyDeviceToHost, st));
   // `order` lives on the host stack: the copy above must have left it before we return
   HIP_TRY(hipStreamSynchronize(st));
   p->have_prepare = true;
@@ -446,6 +453,78 @@ int relate_plan_paint(relate_plan* p, void* d_out, void* stream)
       std::fclose(f);
     }
   }
+  return RELATE_OK;
+}
+
+int relate_plan_repaint_layout(relate_plan* p, int window, int64_t* total_rows, int* pitch, int64_t* row_offsets)
+{
+  if (!p) return fail(RELATE_EINVAL, "null plan");
+  if (p->K <= 0 || !p->have_prepare) return fail(RELATE_EINVAL, "no targets prepared");
+  if (p->variant != 1) return fail(RELATE_EINVAL, "re-painting needs the register-resident kernel (variant 1)");
+  if (window < 0 || window >= p->W) return fail(RELATE_EINVAL, "window out of range");
+  int64_t rows = 0;
+  for (int t = 0; t < p->K; t++) {
+    if (row_offsets) row_offsets[t] = rows;
+    const int n = p->h_bej[(size_t)t * p->W + window] - p->h_bbj[(size_t)t * p->W + window] + 1;
+    if (n < 2) return fail(RELATE_EGPU, "section with fewer than two sites (kernel fault?)");
+    rows += n;
+  }
+  if (row_offsets) row_offsets[p->K] = rows;
+  if (total_rows) *total_rows = rows;
+  if (pitch) *pitch = p->geo.G * p->geo.MPL * 64;
+  return RELATE_OK;
+}
+
+int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* d_topology, void* d_logscales,
+                        void* stream)
+{
+  if (!p || !d_stones || !d_topology || !d_logscales) return fail(RELATE_EINVAL, "null argument");
+  std::vector<int64_t> ro((size_t)std::max(p->K, 0) + 1);
+  int64_t rows = 0;
+  int pitch = 0;
+  if (int rc = relate_plan_repaint_layout(p, window, &rows, &pitch, ro.data())) return rc;
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st = p->pick(stream);
+  const int K = p->K;
+  if (int rc = p->row_off.reserve(sizeof(int64_t) * (size_t)K)) return rc;
+  if (int rc = p->last_coef.reserve(sizeof(double) * (size_t)K)) return rc;
+  if (int rc = p->last_nx.reserve(sizeof(double) * (size_t)K)) return rc;
+  if (int rc = p->scratch.reserve(sizeof(double) * (size_t)rows * pitch)) return rc;
+  HIP_TRY(hipMemcpyAsync(p->row_off.p, ro.data(), sizeof(int64_t) * (size_t)K, hipMemcpyHostToDevice, st));
+  const relate::PaintConsts c = make_consts(p->N, p->theta_p, p->theta_d);
+  HIP_TRY(relate::launch_section_last_terms(p->dk.as<int32_t>(), p->off.as<int64_t>(), p->bej.as<int32_t>(), K, p->W,
+                                            window, p->d_r, c, p->last_coef.as<double>(), p->last_nx.as<double>(), st));
+  relate::RepaintLaunch a;
+  a.rows = p->d_rows;
+  a.row_stride = p->row_stride;
+  a.dk = p->dk.as<int32_t>();
+  a.rec = p->rec.as<relate::SiteRec>();
+  a.off = p->off.as<int64_t>();
+  a.nd = p->nd.as<int32_t>();
+  a.bbj = p->bbj.as<int32_t>();
+  a.bej = p->bej.as<int32_t>();
+  a.order = p->order.as<int32_t>();
+  a.stones = static_cast<const uint8_t*>(d_stones);
+  a.row_off = p->row_off.as<int64_t>();
+  a.last_coef = p->last_coef.as<double>();
+  a.last_nx = p->last_nx.as<double>();
+  a.scratch = p->scratch.as<double>();
+  a.topology = static_cast<float*>(d_topology);
+  a.logscales = static_cast<float*>(d_logscales);
+  a.w = window;
+  a.pitch = pitch;
+  a.N = p->N;
+  a.L = p->L;
+  a.W = p->W;
+  a.k_begin = p->k_begin;
+  a.K = K;
+  a.c = c;
+  HIP_TRY(hipEventRecord(p->ev[4], st));
+  HIP_TRY(relate::launch_repaint(a, p->geo, st));
+  HIP_TRY(hipEventRecord(p->ev[5], st));
+  p->have_paint = true;
+  // the row offsets were copied from a host vector that dies with this call
+  HIP_TRY(hipStreamSynchronize(st));
   return RELATE_OK;
 }
 

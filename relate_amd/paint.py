@@ -144,6 +144,19 @@ class Plan:
     def out_bytes(self):
         return self.W * self.K * record_bytes(self.N)
 
+    def repaint_layout(self, window):
+        """(total_rows, pitch, row_offsets[K+1]) of the topology of one window (RePaintSection for all targets)."""
+        rows, pitch = C.c_int64(), C.c_int()
+        off = np.zeros(self.K + 1, dtype=np.int64)
+        check(lib().relate_plan_repaint_layout(self._h, window, C.byref(rows), C.byref(pitch),
+                                               off.ctypes.data_as(C.POINTER(C.c_int64))))
+        return rows.value, pitch.value, off
+
+    def repaint(self, window, d_stones, d_topology, d_logscales, stream=0):
+        """FastPainting::RePaintSection (src/fast_painting.cpp:654-1126) of every prepared target for one window;
+        d_stones = slab `window` of what paint() wrote (device pointers)."""
+        check(lib().relate_plan_repaint(self._h, window, vp(d_stones), vp(d_topology), vp(d_logscales), vp(stream)))
+
     def timings(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         check(lib().relate_plan_timings(self._h, C.byref(a), C.byref(b), C.byref(c)))

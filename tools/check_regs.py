@@ -4,7 +4,7 @@
 The kernels keep their state in VGPRs >= 48 and their row buffers in SGPRs >= 60, addressed by number
 from inline asm, and rely on the compiler staying below those limits.  This script reads the device
 assembly (hipcc -S --cuda-device-only) of the instantiation files and fails if any instruction the
-COMPILER emitted (i.e. outside the asm statements) inside a paint_kernel_r kernel names v48+ or s60+.
+COMPILER emitted (i.e. outside the asm statements) inside a paint_kernel_r / repaint_kernel_r kernel names v48+ or s60+.
 
     python tools/check_regs.py relate_amd/csrc/paint_regs_g1.s ...
 """
@@ -21,7 +21,7 @@ def check(path):
     in_asm = False
     counts = {}
     for ln, line in enumerate(open(path), 1):
-        m = re.match(r"^(_ZN6relate4regs14paint_kernel_r\w+):", line)
+        m = re.match(r"^(_ZN6relate4regs\d+(?:paint|repaint)_kernel_r\w+):", line)
         if m:
             kernel = m.group(1)
             counts[kernel] = 0
