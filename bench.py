@@ -59,6 +59,40 @@ def cpu_baseline(seq, r, wb, theta, budget_s=15.0):
             "sample": f"{ks} of {N} targets of the same chunk, {dt:.1f} s on one core"}
 
 
+def repaint_leg(plan, torch, d_out, w, N, R, stream, reps=3):
+    """Re-painting of one window from the stones the timed steps left in HBM: per element of the topology
+    matrix the two launches write an alpha (8 B), read it back (8 B) and write the product (4 B)."""
+    rows, pitch, _ = plan.repaint_layout(w)
+    top = torch.empty(rows * pitch, dtype=torch.float32, device="cuda")
+    ls = torch.empty(rows, dtype=torch.float32, device="cuda")
+    ms = []
+    for _ in range(reps):
+        plan.repaint(w, d_out.data_ptr() + w * N * R, top.data_ptr(), ls.data_ptr(), stream)
+        ms.append(plan.timings()["paint_ms"])
+    t = min(ms) * 1e-3
+    b_alg = 20.0 * rows * N
+    out = {"window": w, "rows": rows, "pitch": pitch, "ms": min(ms), "elements_per_s": rows * N / t,
+           "roofline": {"bound": "hbm", "achieved": b_alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": b_alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    # distance matrix of one SNP from that topology (DistanceMeasure::GetMatrix): every other row mixed with
+    # its successor; reads one or two topology rows per matrix row, writes N x N floats
+    _, _, off = plan.repaint_layout(w)
+    mat = torch.empty(N * N, dtype=torch.float32, device="cuda")
+    interp = (np.arange(N) & 1).astype(np.uint8)
+    half = np.full(N, 0.5)
+    ms = []
+    for _ in range(reps + 2):
+        plan.distance_matrix(N, top.data_ptr(), pitch, ls.data_ptr(), rows, off[:N], interp, half, half, mat.data_ptr(),
+                             stream)
+        ms.append(plan.timings()["paint_ms"])
+    t = min(ms) * 1e-3
+    b_dm = 4.0 * N * N + 4.0 * N * N * 1.5
+    out["distance_matrix"] = {"ms": min(ms), "roofline": {"bound": "hbm", "achieved": b_dm / t / 1e9, "peak": HBM_PEAK_GBS,
+                                                          "unit": "GB/s", "frac": b_dm / t / 1e9 / HBM_PEAK_GBS,
+                                                          "traffic": None}}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +102,8 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="waves per target (0 = automatic)")
     ap.add_argument("--variant", type=int, default=1, help="recursion kernel: 1 register-resident, 0 plain HIP cross-check")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--repaint", type=int, default=-1, metavar="W",
+                    help="also time the re-painting (RePaintSection of all targets) of window W; adds a 'repaint' object")
     ap.add_argument("--N", type=int, default=0, help="override the number of haplotypes (experiments)")
     ap.add_argument("--L", type=int, default=0, help="override the number of SNPs (experiments)")
     args = ap.parse_args()
@@ -184,6 +220,8 @@ def main():
             "roofline_hbm": {"bound": "hbm", "achieved": b_alg / t_paint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": b_alg / t_paint / 1e9 / HBM_PEAK_GBS, "traffic": traffic},
         }
+        if args.repaint >= 0 and kb >= N:
+            out["repaint"] = repaint_leg(plan, torch, d_out, args.repaint, N, R, stream)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(seq, r, wb, theta)
         print(json.dumps(out))

@@ -152,6 +152,19 @@ int relate_plan_paint(relate_plan* p, void* d_out, void* stream);
 int relate_plan_repaint_layout(relate_plan* p, int window, int64_t* total_rows, int* pitch, int64_t* row_offsets);
 int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* d_topology, void* d_logscales,
                         void* stream);
+/* The distance matrix of one SNP from a device-resident topology:
+ *   void DistanceMeasure::GetMatrix(const int snp)  (src/anc_builder.cpp:113-211), the part after the
+ * topology has been loaded (:120-196).  The caller keeps the reference's bookkeeping (v_snp_prev, v_rpos_prev,
+ * v_rpos_next, src/anc_builder.cpp:85-105,:144-161) and passes, for every row n, host arrays:
+ *   row_index[n]   = row_offsets[n] + v_snp_prev[n] (row of relate_plan_repaint's topology),
+ *   interpolate[n] = 0 where the reference takes that row as is (n carries the derived allele at snp, or snp
+ *                    is the first or last SNP), 1 where it mixes rows row_index[n] and row_index[n]+1,
+ *   weight_left[n], weight_right[n] = the two weights of that mix (:152-161; ignored where interpolate[n] == 0).
+ * d_matrix receives N x N floats, row n = distances from n (matrix[n][m] of the reference), row minimum
+ * subtracted, zero diagonal.  total_rows bounds the row indices. */
+int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, int pitch, const void* d_logscales,
+                                int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
+                                const double* weight_left, const double* weight_right, void* d_matrix, void* stream);
 /* Milliseconds of the last pack / prepare / paint, from HIP events on the stream they ran on
  * (blocks until the paint has finished); after relate_plan_repaint, ms_paint is the time of its two launches. */
 int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float* ms_paint);

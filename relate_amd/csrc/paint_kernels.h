@@ -82,6 +82,11 @@ hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const
 // variant: 0 = plain HIP recursion (cross-check, N <= 4096), 1 = register-resident recursion
 hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStream_t st);
 hipError_t launch_fast_log(const float* d_in, float* d_out, int n, hipStream_t st);
+// DistanceMeasure::GetMatrix (src/anc_builder.cpp:113-211) on a device-resident topology: row n of `matrix`
+// from topology row `row[n]` (and the next one where interp[n] != 0, with weights wl[n], wr[n]).
+hipError_t launch_distance_matrix(const float* d_top, int pitch, const float* d_ls, const int64_t* d_row,
+                                  const uint8_t* d_interp, const double* d_wl, const double* d_wr, int N,
+                                  float* d_matrix, hipStream_t st);
 
 // Re-painting of one window from its stones (register-resident kernels, repaint_regs.hpp).
 struct RepaintLaunch {

@@ -34,6 +34,72 @@ __global__ void fast_log_kernel(const float* __restrict__ in, float* __restrict_
   if (i < n) out[i] = fast_log_dev(in[i]);
 }
 
+// ------------------------------------------------------------------ distance matrix
+// DistanceMeasure::GetMatrix (src/anc_builder.cpp:113-211).  One workgroup per row n of the N x N matrix:
+//   direct rows (n carries the derived allele at the SNP, or the SNP is the first / last of the chunk):
+//     d = (fast_log(top[m]) + logscale) * scale                                   (:122-141)
+//   other rows: the two topology rows around the SNP are mixed in probability space with the weights
+//     of the genetic distances, rescaled to the larger of the two logscales        (:143-193)
+//   then d[n][n] = 0 and the row minimum -- taken over all m, the diagonal's own value included, as
+//   the reference does -- is subtracted from the off-diagonal entries              (:194-196).
+// The arithmetic keeps the reference's types: weights in double, the mix in double, narrowed to float
+// for fast_log, float from there on; scale = -1.0f (src/anc_builder.hpp:46).
+__device__ __forceinline__ float distance_entry(bool interp, bool prev_le_next, float tp, float tn, double wl, double wr,
+                                                float e_pn, float e_np, float ls_prev, float ls_next)
+{
+  const float scale = -1.0f;
+  if (!interp) return __fmul_rn(__fadd_rn(fast_log_dev(tp), ls_prev), scale);
+  if (prev_le_next) {
+    const double x = __dadd_rn(__dmul_rn(__dmul_rn(wl, (double)tp), (double)e_pn), __dmul_rn(wr, (double)tn));
+    return __fmul_rn(__fadd_rn(fast_log_dev((float)x), ls_next), scale);
+  }
+  const double x = __dadd_rn(__dmul_rn(wl, (double)tp), __dmul_rn(__dmul_rn(wr, (double)tn), (double)e_np));
+  return __fmul_rn(__fadd_rn(fast_log_dev((float)x), ls_prev), scale);
+}
+
+__global__ void __launch_bounds__(256) distance_matrix_kernel(const float* __restrict__ top, int pitch,
+                                                              const float* __restrict__ ls,
+                                                              const int64_t* __restrict__ row,
+                                                              const uint8_t* __restrict__ interp_flag,
+                                                              const double* __restrict__ wl_all,
+                                                              const double* __restrict__ wr_all, int N,
+                                                              float* __restrict__ matrix)
+{
+  __shared__ float smin[4];
+  const int n = blockIdx.x;
+  const long long r0 = row[n];
+  const bool interp = interp_flag[n] != 0;
+  const float* __restrict__ tp = top + r0 * pitch;
+  const float* __restrict__ tn = tp + (interp ? pitch : 0);
+  const float ls_prev = ls[r0];
+  const float ls_next = interp ? ls[r0 + 1] : ls_prev;
+  const double wl = interp ? wl_all[n] : 0.0, wr = interp ? wr_all[n] : 0.0;
+  // `exp(float)` written unqualified in the reference (:171-172): the double function, narrowed on assignment
+  const float e_pn = (float)exp((double)__fsub_rn(ls_prev, ls_next)), e_np = (float)exp((double)__fsub_rn(ls_next, ls_prev));
+  const bool prev_le_next = ls_prev <= ls_next;
+  float mn = __builtin_inff();
+  for (int m = threadIdx.x; m < N; m += 256) {
+    const float v = distance_entry(interp, prev_le_next, tp[m], tn[m], wl, wr, e_pn, e_np, ls_prev, ls_next);
+    if (v < mn) mn = v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float other = __shfl_xor(mn, o, 64);
+    if (other < mn) mn = other;
+  }
+  if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = mn;
+  __syncthreads();
+  mn = smin[0];
+#pragma unroll
+  for (int i = 1; i < 4; i++)
+    if (smin[i] < mn) mn = smin[i];
+  float* __restrict__ out = matrix + (long long)n * N;
+  for (int m = threadIdx.x; m < N; m += 256) {
+    const float v = distance_entry(interp, prev_le_next, tp[m], tn[m], wl, wr, e_pn, e_np, ls_prev, ls_next);
+    out[m] = (m == n) ? 0.0f : __fsub_rn(v, mn);
+  }
+}
+
 // ------------------------------------------------------------------ packing
 // chunk_<c>.hap rows ('0'/'1' bytes, src/data.cpp:541-550) -> bit rows.  One wave
 // per output word: 64 coalesced bytes in, one ballot, one 8-byte store.
@@ -512,6 +578,15 @@ hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const
   const long long n = (long long)K * W;
   hipLaunchKernelGGL(window_stones_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_dk, d_off, d_nd, K,
                      W, d_wb, d_bbj, d_bej);
+  return hipGetLastError();
+}
+
+hipError_t launch_distance_matrix(const float* d_top, int pitch, const float* d_ls, const int64_t* d_row,
+                                  const uint8_t* d_interp, const double* d_wl, const double* d_wr, int N,
+                                  float* d_matrix, hipStream_t st)
+{
+  hipLaunchKernelGGL(distance_matrix_kernel, dim3(N), dim3(256), 0, st, d_top, pitch, d_ls, d_row, d_interp, d_wl, d_wr, N,
+                     d_matrix);
   return hipGetLastError();
 }
 

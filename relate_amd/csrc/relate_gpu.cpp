@@ -134,6 +134,7 @@ struct relate_plan {
   // re-painting
   std::vector<int32_t> h_bbj, h_bej;  // host copies of the stone indices, [K][W]
   DevBuf row_off, last_coef, last_nx, scratch;
+  DevBuf dm_args;  // per-row arguments of the distance-matrix kernel
   std::vector<int32_t> h_nd;
   std::vector<int64_t> h_off;
   int64_t sum_nd = 0;
@@ -208,7 +209,7 @@ void relate_plan_destroy(relate_plan* p)
   if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
   if (!p->packed_borrowed) p->packed.release();
   for (DevBuf* b : {&p->seq_own, &p->r_own, &p->wb_dev, &p->nd, &p->off, &p->dk, &p->coef, &p->nx, &p->bbj, &p->bej,
-                    &p->order, &p->trace, &p->rec, &p->row_off, &p->last_coef, &p->last_nx, &p->scratch})
+                    &p->order, &p->trace, &p->rec, &p->row_off, &p->last_coef, &p->last_nx, &p->scratch, &p->dm_args})
     b->release();
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
@@ -525,6 +526,48 @@ int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* 
   p->have_paint = true;
   // the row offsets were copied from a host vector that dies with this call
   HIP_TRY(hipStreamSynchronize(st));
+  return RELATE_OK;
+}
+
+int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, int pitch, const void* d_logscales,
+                                int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
+                                const double* weight_left, const double* weight_right, void* d_matrix, void* stream)
+{
+  if (!p || !d_topology || !d_logscales || !row_index || !interpolate || !d_matrix)
+    return fail(RELATE_EINVAL, "null argument");
+  if (N < 1 || pitch < N) return fail(RELATE_EINVAL, "bad matrix size or pitch");
+  for (int n = 0; n < N; n++) {
+    if (interpolate[n] && (!weight_left || !weight_right)) return fail(RELATE_EINVAL, "interpolated rows need weights");
+    if (row_index[n] < 0 || row_index[n] + (interpolate[n] ? 1 : 0) >= total_rows)
+      return fail(RELATE_EINVAL, "topology row index out of range");
+  }
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st = p->pick(stream);
+  // one staging block: row indices, weights, flags
+  const size_t nb = (size_t)N * (8 + 8 + 8) + (size_t)N;
+  std::vector<uint8_t> h(nb);
+  int64_t* hr = reinterpret_cast<int64_t*>(h.data());
+  double* hl = reinterpret_cast<double*>(h.data() + (size_t)8 * N);
+  double* hw = reinterpret_cast<double*>(h.data() + (size_t)16 * N);
+  uint8_t* hf = h.data() + (size_t)24 * N;
+  for (int n = 0; n < N; n++) {
+    hr[n] = row_index[n];
+    hl[n] = interpolate[n] ? weight_left[n] : 0.0;
+    hw[n] = interpolate[n] ? weight_right[n] : 0.0;
+    hf[n] = interpolate[n] ? 1 : 0;
+  }
+  if (int rc = p->dm_args.reserve(nb)) return rc;
+  HIP_TRY(hipMemcpyAsync(p->dm_args.p, h.data(), nb, hipMemcpyHostToDevice, st));
+  uint8_t* d = static_cast<uint8_t*>(p->dm_args.p);
+  HIP_TRY(hipEventRecord(p->ev[4], st));
+  HIP_TRY(relate::launch_distance_matrix(static_cast<const float*>(d_topology), pitch,
+                                         static_cast<const float*>(d_logscales), reinterpret_cast<const int64_t*>(d),
+                                         d + (size_t)24 * N, reinterpret_cast<const double*>(d + (size_t)8 * N),
+                                         reinterpret_cast<const double*>(d + (size_t)16 * N), N,
+                                         static_cast<float*>(d_matrix), st));
+  HIP_TRY(hipEventRecord(p->ev[5], st));
+  p->have_paint = true;
+  HIP_TRY(hipStreamSynchronize(st));  // the staging vector dies with this call
   return RELATE_OK;
 }
 

@@ -157,6 +157,18 @@ class Plan:
         d_stones = slab `window` of what paint() wrote (device pointers)."""
         check(lib().relate_plan_repaint(self._h, window, vp(d_stones), vp(d_topology), vp(d_logscales), vp(stream)))
 
+    def distance_matrix(self, N, d_topology, pitch, d_logscales, total_rows, row_index, interpolate, weight_left,
+                        weight_right, d_matrix, stream=0):
+        """DistanceMeasure::GetMatrix (src/anc_builder.cpp:113-211) for one SNP; per-row arguments are host arrays."""
+        ri = np.ascontiguousarray(row_index, dtype=np.int64)
+        fl = np.ascontiguousarray(interpolate, dtype=np.uint8)
+        wl = np.ascontiguousarray(weight_left, dtype=np.float64)
+        wr = np.ascontiguousarray(weight_right, dtype=np.float64)
+        check(lib().relate_plan_distance_matrix(self._h, N, vp(d_topology), pitch, vp(d_logscales), total_rows,
+                                                ri.ctypes.data_as(i64p), fl.ctypes.data_as(u8p),
+                                                wl.ctypes.data_as(f64p), wr.ctypes.data_as(f64p), vp(d_matrix),
+                                                vp(stream)))
+
     def timings(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         check(lib().relate_plan_timings(self._h, C.byref(a), C.byref(b), C.byref(c)))

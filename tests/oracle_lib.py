@@ -94,6 +94,24 @@ def oracle():
     return _oracle
 
 
+def distance_matrix(top, ls, row, interp, wl, wr, N):
+    """oracle_distance_matrix (restated DistanceMeasure::GetMatrix, parity unpinned): top is rows x pitch."""
+    lib = oracle().lib
+    f = lib.oracle_distance_matrix
+    f.restype = None
+    f.argtypes = [C.c_int, _f32p, C.c_int, _f32p, C.POINTER(C.c_int64), _u8p, _f64p, _f64p, _f32p]
+    top = np.ascontiguousarray(top, dtype=np.float32)
+    ls = np.ascontiguousarray(ls, dtype=np.float32)
+    row = np.ascontiguousarray(row, dtype=np.int64)
+    interp = np.ascontiguousarray(interp, dtype=np.uint8)
+    wl = np.ascontiguousarray(wl, dtype=np.float64)
+    wr = np.ascontiguousarray(wr, dtype=np.float64)
+    out = np.zeros((N, N), dtype=np.float32)
+    f(N, _ptr(top, _f32p), top.shape[1], _ptr(ls, _f32p), row.ctypes.data_as(C.POINTER(C.c_int64)), _ptr(interp, _u8p),
+      _ptr(wl, _f64p), _ptr(wr, _f64p), _ptr(out, _f32p))
+    return out
+
+
 def count_derived(seq):
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
     L, N = seq.shape

@@ -1,0 +1,90 @@
+"""GPU parity of the distance matrix (DistanceMeasure::GetMatrix, src/anc_builder.cpp:113-211) on a topology
+that stays in HBM: the window is re-painted on the GPU, the per-row bookkeeping of the reference (which
+topology row precedes the SNP, whether the row is taken as is or mixed with the next, the two weights) is
+restated here on the host, and the N x N matrix of the GPU kernel is compared with the CPU oracle fed with
+the same (downloaded) topology.
+
+The oracle of this function is a restatement without a compiled reference behind it (parity unpinned, see
+oracle/distance_oracle.c).  Bar: rows taken as is bit-exact (fast_log and float arithmetic only); mixed rows
+within 1e-5 (they involve one exp per row)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth_np as sy
+from test_gpu_repaint import _ra
+
+pytestmark = pytest.mark.gpu
+
+
+def bookkeeping(seq, rpos, wb, w, snp, a_snp, off):
+    """v_snp_prev / interpolation flags / weights of src/anc_builder.cpp:85-105,:122,:144-161 for one SNP of
+    window w.  a_snp[n] = site of target n's alpha stone (row 0 of its topology)."""
+    L, N = seq.shape
+    der = seq == ord("1")
+    row = np.zeros(N, dtype=np.int64)
+    interp = np.zeros(N, dtype=np.uint8)
+    wl = np.zeros(N)
+    wr = np.zeros(N)
+    for n in range(N):
+        # rows of target n: its alpha-stone site, then every derived site after it
+        v = int(der[a_snp[n] + 1:snp + 1, n].sum())
+        row[n] = off[n] + v
+        if der[snp, n] or snp == 0 or snp == L - 1:
+            continue
+        interp[n] = 1
+        t = snp
+        while not der[t, n] and t > 0:
+            t -= 1
+        rp = rpos[t]
+        nxt = snp
+        while not (der[nxt, n] or nxt == L - 1):
+            nxt += 1
+        rn = rpos[nxt]
+        if rp == rn:
+            wl[n] = wr[n] = 0.5
+        else:
+            wl[n] = (rn - rpos[snp]) / (rn - rp)
+            wr[n] = (rpos[snp] - rp) / (rn - rp)
+    return row, interp, wl, wr
+
+
+@pytest.mark.parametrize("N,L,W,seed,theta", [(70, 1200, 3, 51, 0.001), (200, 900, 2, 52, 0.01), (513, 600, 2, 53, 0.001)])
+def test_distance_matrix_matches_oracle(N, L, W, seed, theta):
+    import torch
+    ra = _ra()
+    seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=seed, r_mode="flat")
+    rpos = np.concatenate([[0.0], np.cumsum(r / 2500.0)])  # genetic positions consistent with r (src/data.cpp:484-488)
+    plan = ra.Plan(0, 1, 0)
+    plan.load_host(seq, r, wb)
+    plan.prepare(theta, theta, 0, N)
+    stones = torch.zeros(plan.out_bytes(), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    plan.paint(stones.data_ptr())
+    plan.timings()
+    R = ra.record_bytes(N)
+    for w in range(W):
+        rows, pitch, off = plan.repaint_layout(w)
+        top = torch.zeros((rows, pitch), dtype=torch.float32, device="cuda:0")
+        ls = torch.zeros((rows,), dtype=torch.float32, device="cuda:0")
+        mat = torch.zeros((N, N), dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        plan.repaint(w, stones.data_ptr() + w * N * R, top.data_ptr(), ls.data_ptr())
+        d = ol.decode_records(stones.cpu().numpy().reshape(plan.W, N, R)[w:w + 1])
+        a_snp = d["a_snp"][0]
+        h_top, h_ls = top.cpu().numpy(), ls.cpu().numpy()
+        lo, hi = int(wb[w]), int(wb[w + 1]) - 1
+        for snp in sorted({lo, (lo + hi) // 2, hi, min(hi, lo + 7)}):
+            row, interp, wl, wr = bookkeeping(seq, rpos, wb, w, snp, a_snp, off)
+            assert np.all(row + interp < off[1:]), "bookkeeping left the section"
+            plan.distance_matrix(N, top.data_ptr(), pitch, ls.data_ptr(), rows, row, interp, wl, wr, mat.data_ptr())
+            got = mat.cpu().numpy()
+            want = ol.distance_matrix(h_top, h_ls, row, interp, wl, wr, N)
+            assert np.isfinite(got).all()
+            assert (np.diag(got) == 0).all()
+            direct = interp == 0
+            assert np.array_equal(got[direct].view(np.uint32), want[direct].view(np.uint32)), f"w{w} snp{snp}: direct rows"
+            assert np.all(np.abs(got - want) <= 1e-5 * np.maximum(1.0, np.abs(want))), f"w{w} snp{snp}: mixed rows"
+            offdiag = ~np.eye(N, dtype=bool)
+            assert np.all(got[offdiag].reshape(N, N - 1).min(axis=1) <= 1e-4), "row minimum was not subtracted"
+    plan.close()

@@ -100,3 +100,39 @@ def test_oracle_matches_compiled_reference_live(seed):
         a = ol.oracle().paint_stones(seq, r, tp, td, wb)
         b = ol.ref().paint_stones(seq, r, tp, td, wb)
         assert np.array_equal(a, b)
+
+
+def test_distance_oracle_against_numpy_restatement():
+    """oracle_distance_matrix (src/anc_builder.cpp:120-196 restated in C; parity unpinned, see its header) against
+    the same expressions written with numpy and the oracle's fast_log."""
+    rng = np.random.default_rng(3)
+    N, rows, pitch = 9, 30, 16
+    top = np.zeros((rows, pitch), dtype=np.float32)
+    top[:, :N] = np.exp(rng.uniform(-60, 0, (rows, N))).astype(np.float32)
+    ls = rng.uniform(-300, 5, rows).astype(np.float32)
+    row = rng.integers(0, rows - 1, N).astype(np.int64)
+    interp = (rng.random(N) < 0.5).astype(np.uint8)
+    wl = rng.random(N)
+    wr = 1.0 - wl
+    for n in range(N):
+        top[row[n], n] = 0.0  # a target's own entry
+    got = ol.distance_matrix(top, ls, row, interp, wl, wr, N)
+    fl = ol.oracle().fast_log
+    f32 = np.float32
+    for n in range(N):
+        vals = np.zeros(N, dtype=np.float32)
+        for m in range(N):
+            tp, tn = top[row[n], m], top[row[n] + 1, m]
+            lp, ln = ls[row[n]], ls[row[n] + 1]
+            if not interp[n]:
+                vals[m] = (f32(fl(float(tp))) + lp) * f32(-1.0)
+            elif lp <= ln:
+                x = wl[n] * float(tp) * float(f32(np.exp(np.float64(f32(lp - ln))))) + wr[n] * float(tn)
+                vals[m] = (f32(fl(float(f32(x)))) + ln) * f32(-1.0)
+            else:
+                x = wl[n] * float(tp) + wr[n] * float(tn) * float(f32(np.exp(np.float64(f32(ln - lp)))))
+                vals[m] = (f32(fl(float(f32(x)))) + lp) * f32(-1.0)
+        mn = vals.min()
+        want = vals - mn
+        want[n] = 0.0
+        assert np.array_equal(got[n].view(np.uint32), want.view(np.uint32)), n
