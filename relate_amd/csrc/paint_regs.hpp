@@ -7,7 +7,7 @@
 // Hence no spills, no copies at control-flow joins, and the sweep over the states is straight-line
 // code:
 //   forward   a' = (a + rx) * (mismatch ? rho : 1)           add, masked mul, accumulate  (3 per 64 states)
-//   backward  b' = mismatch' ? fma(b, rho, c1) : b + add_all masked fma, masked add,
+//   backward  t = b + add_all; b' = mismatch' ? fma(t, rho, c1) : t   add, masked fma,
 //             sums of b' over all / over mismatching states  accumulate, masked accumulate (4 per 64 states)
 // "masked" = the bit-row word of the site (an SGPR pair fed by s_load_dwordx8, double-buffered one
 // 4-word batch ahead) written into EXEC, so the emission costs no vector instruction.
@@ -309,10 +309,9 @@ __device__ __forceinline__ void fwd_batch(double& c0, double& c1, double rx, dou
 #undef RELATE_FWD_OPS
 }
 
+#define RELATE_BWD_ADD(i) "v_add_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[aa]\n\t"
 #define RELATE_BWD_FMA(i) \
   "s_andn2_b64 exec, %[skn], " RELATE_W(sn, i) "\n\tv_fma_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[rho], %[c1]\n\t"
-#define RELATE_BWD_ADD(i) \
-  "s_orn2_b64 exec, " RELATE_W(sn, i) ", %[skn]\n\tv_add_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[aa]\n\t"
 #define RELATE_BWD_ALL(c, i) "v_add_f64 %[" #c "], %[" #c "], " RELATE_A(i) "\n\t"
 #define RELATE_BWD_SET(c, i) "v_mov_b64 %[" #c "], " RELATE_A(i) "\n\t"
 #define RELATE_BWD_MIS(c, i) \
@@ -335,33 +334,33 @@ __device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, doub
     [sn] "n"(SN), [sc] "n"(SC)                                                                                 \
   : "scc"
   if constexpr (NW == 4 && FIRST)
-    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3)
-                 RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2) RELATE_BWD_ADD(3)
+    asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2) RELATE_BWD_ADD(3)
+                 RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3)
                  "s_mov_b64 exec, -1\n\t"
                  RELATE_BWD_SET(ca0, 0) RELATE_BWD_SET(ca1, 1) RELATE_BWD_ALL(ca0, 2) RELATE_BWD_ALL(ca1, 3)
                  RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2) RELATE_BWD_MIS(cm1, 3)
                  "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
   else if constexpr (NW == 4)
-    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3)
-                 RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2) RELATE_BWD_ADD(3)
+    asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2) RELATE_BWD_ADD(3)
+                 RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3)
                  "s_mov_b64 exec, -1\n\t"
                  RELATE_BWD_ALL(ca0, 0) RELATE_BWD_ALL(ca1, 1) RELATE_BWD_ALL(ca0, 2) RELATE_BWD_ALL(ca1, 3)
                  RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2) RELATE_BWD_MIS(cm1, 3)
                  "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
   else if constexpr (NW == 3)
-    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2)
-                 RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2)
+    asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2)
+                 RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2)
                  "s_mov_b64 exec, -1\n\t"
                  RELATE_BWD_ALL(ca0, 0) RELATE_BWD_ALL(ca1, 1) RELATE_BWD_ALL(ca0, 2)
                  RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2)
                  "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
   else if constexpr (NW == 2)
-    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_ADD(0) RELATE_BWD_ADD(1)
+    asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_FMA(0) RELATE_BWD_FMA(1)
                  "s_mov_b64 exec, -1\n\t"
                  RELATE_BWD_ALL(ca0, 0) RELATE_BWD_ALL(ca1, 1) RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1)
                  "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
   else
-    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_ADD(0) "s_mov_b64 exec, -1\n\t" RELATE_BWD_ALL(ca0, 0) RELATE_BWD_MIS(cm0, 0)
+    asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_FMA(0) "s_mov_b64 exec, -1\n\t" RELATE_BWD_ALL(ca0, 0) RELATE_BWD_MIS(cm0, 0)
                  "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
 #undef RELATE_BWD_OPS
 }
@@ -451,11 +450,11 @@ __device__ __forceinline__ double block_sum_regs(double (*red)[G], int& slot, Pa
 // wave therefore rotates its own priority with its progress (rank = its slot on the SIMD, i.e. its age
 // rank): all four see the same sequence of priorities and advance at the same average rate.
 // The backward pass has 4/3 of the work of the forward pass per site, so its waves (`bias` 1) move up
-// one level half of the time and the two kinds end closer together.
+// one level three quarters of the time and the two kinds end closer together.
 __device__ __forceinline__ void rotate_priority(int rank, int j, int bias)
 {
   int level = (rank + (j >> 5)) & 3;
-  if (bias && ((j >> 7) & 1) && level < 3) level++;
+  if (bias && ((j >> 7) & 3) && level < 3) level++;
   switch (level) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
     case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -696,11 +695,11 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     for (int j = nd - 2; j >= 0; j--) {
       if ((j & 31) == 0) rotate_priority(rank, j, 1);
       // beta' = (beta + mis'*b + a) * (mis' ? rho : 1), a = rx/(1-theta), b = rx/theta - a (:488-502), as
-      // matching states: beta + a; mismatching states: fma(beta, rho, (b + a)*rho)
+      // t = beta + a for every state, then fma(t, rho, b*rho) for the mismatching ones
       const double rx = B * coef_j;
       const double aa = rx * inv_nt;
       const double bb = rx * inv_t - aa;
-      const double c1 = (bb + aa) * rho;
+      const double c1 = bb * rho;
       write_stateless<MPL>(rx, inv_nt, z.selfm, z.selfidx, z.phm, z.phidx);
       // scalars of the step to site j-1 travel during this sweep
       prefetch_site<false>();

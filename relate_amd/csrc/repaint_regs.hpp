@@ -225,7 +225,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
       const double rx = B * coef_j;
       const double aa = rx * inv_nt;
       const double bb = rx * inv_t - aa;
-      const double c1 = (bb + aa) * rho;
+      const double c1 = bb * rho;
       write_stateless<MPL>(rx, inv_nt, z.selfm, z.selfidx, z.phm, z.phidx);
       prefetch_site<false>();
       const uint64_t skn = edge_select(j, nds - 2, sk_last);
