@@ -634,6 +634,53 @@ int batch_targets(int N, int W, size_t budget)
   return (int)k;
 }
 
+// Pinned staging memory for the copy back of the records.  Pinning a few hundred megabytes costs as much as
+// painting a chunk, so one block is kept for the life of the process and handed to one caller at a time
+// (a second concurrent caller pins a block of its own).
+struct PinnedCache {
+  std::mutex m;
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool busy = false;
+};
+PinnedCache g_pinned;
+
+struct PinnedLease {
+  void* p = nullptr;
+  bool cached = false;
+  int acquire(size_t bytes)
+  {
+    {
+      std::lock_guard<std::mutex> lk(g_pinned.m);
+      if (!g_pinned.busy) {
+        if (g_pinned.bytes < bytes) {
+          if (g_pinned.p) (void)hipHostFree(g_pinned.p);
+          g_pinned.p = nullptr;
+          g_pinned.bytes = 0;
+          if (hipHostMalloc(&g_pinned.p, bytes, hipHostMallocDefault) != hipSuccess)
+            return fail(RELATE_ENOMEM, "pinned host allocation failed");
+          g_pinned.bytes = bytes;
+        }
+        g_pinned.busy = true;
+        p = g_pinned.p;
+        cached = true;
+        return RELATE_OK;
+      }
+    }
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return fail(RELATE_ENOMEM, "pinned host allocation failed");
+    return RELATE_OK;
+  }
+  ~PinnedLease()
+  {
+    if (cached) {
+      std::lock_guard<std::mutex> lk(g_pinned.m);
+      g_pinned.busy = false;
+    } else if (p) {
+      (void)hipHostFree(p);
+    }
+  }
+};
+
 // sink(w, k0, nk, ptr): the records of targets [k0, k0+nk) of window w, contiguous at ptr (host memory).
 template <class Sink>
 int paint_range(relate_plan* p, double theta_p, double theta_d, int k_begin, int k_end, Sink&& sink)
@@ -646,13 +693,14 @@ int paint_range(relate_plan* p, double theta_p, double theta_d, int k_begin, int
   size_t budget = std::min<size_t>(free_b / 3, (size_t)24 << 30);
   const int kb = batch_targets(N, W, budget);
   DevBuf d_out;
-  void* h_out = nullptr;
   const size_t batch_bytes = R * (size_t)W * (size_t)std::min(kb, k_end - k_begin);
   if (int rc = d_out.reserve(batch_bytes)) return rc;
-  if (hipHostMalloc(&h_out, batch_bytes, hipHostMallocDefault) != hipSuccess) {
+  PinnedLease lease;
+  if (int rc = lease.acquire(batch_bytes)) {
     d_out.release();
-    return fail(RELATE_ENOMEM, "pinned host allocation failed");
+    return rc;
   }
+  void* h_out = lease.p;
   int rc = RELATE_OK;
   for (int k0 = k_begin; k0 < k_end && rc == RELATE_OK; k0 += kb) {
     const int k1 = std::min(k_end, k0 + kb), nk = k1 - k0;
@@ -669,7 +717,6 @@ int paint_range(relate_plan* p, double theta_p, double theta_d, int k_begin, int
     for (int w = 0; w < W && rc == RELATE_OK; w++)
       rc = sink(w, k0, nk, static_cast<const uint8_t*>(h_out) + (size_t)w * nk * R);
   }
-  (void)hipHostFree(h_out);
   d_out.release();
   return rc;
 }
