@@ -112,6 +112,8 @@ def test_entry_point_host_buffers_matches_golden():
     (1000, 1200, 4, 25, "skew", 1e-4, 1e-4, 4),
     (2048, 600, 2, 26, "flat", 0.001, 0.001, 0),     # N a multiple of 64: no partial word
     (2, 50, 2, 27, "flat", 0.01, 0.01, 0),           # smallest N
+    (2500, 260, 2, 28, "flat", 0.001, 0.001, 0),     # 40 words: two waves per target chosen automatically
+    (5008, 200, 2, 29, "skew", 0.001, 0.001, 0),     # 1000 Genomes panel size: four waves per target
 ])
 def test_against_oracle(N, L, W, seed, mode, tp, td, waves):
     seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=seed, r_mode=mode, empty_window=(W >= 3))
