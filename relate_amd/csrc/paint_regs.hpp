@@ -109,7 +109,7 @@ RELATE_CLAIM(64)
 RELATE_CLAIM(72)
 RELATE_CLAIM(80)
 #undef RELATE_CLAIM
-static_assert(kCV == 48 && kA0 == 56 && kCS == 60, "the clobber lists above are written for this register map");
+static_assert(kCV == 48 && kA0 == 56 && kCS == 60, "the clobber lists above are written for this register map (tools/gen_clobbers.py 48 56 60)");
 
 // A wave-uniform value as an SGPR (the compiler's readfirstlane may be folded into a VGPR copy).
 __device__ __forceinline__ uint32_t sgpr32(uint32_t x)
@@ -510,7 +510,9 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
   // every power-of-two stride of the dispatcher (XCDs, CUs, SIMDs) sees both kinds.
   const int pass = __builtin_popcount(blockIdx.x) & 1;
   const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();
-  const int rank = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3;  // HW_ID.wave_id: slot of this wave on its SIMD
+  // slot of this wave on its SIMD (HW_ID.wave_id); the waves of a multi-wave workgroup meet at a barrier
+  // every site and must share one schedule, so they take it from the block index instead
+  const int rank = G == 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 3) : (int)((blockIdx.x >> 1) & 3);
   const int t = __builtin_amdgcn_readfirstlane(ka.order[blockIdx.x >> 1]);
   const int k = ka.p.k_begin + t;
   const int lane = lane_id();
