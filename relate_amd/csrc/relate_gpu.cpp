@@ -161,6 +161,7 @@ int plan_set_chunk(relate_plan* p, int N, int L, int W, const int32_t* wb, hipSt
   if (int rc = p->wb_dev.reserve(sizeof(int32_t) * (W + 1))) return rc;
   HIP_TRY(hipMemcpyAsync(p->wb_dev.p, p->wb.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice, st));
   p->K = 0;
+  p->have_prepare = false;
   return RELATE_OK;
 }
 

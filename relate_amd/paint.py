@@ -86,7 +86,7 @@ class Plan:
         self._h = vp()
         check(lib().relate_plan_create(device, C.byref(self._h)))
         check(lib().relate_plan_configure(self._h, variant, waves_per_target))
-        self.N = self.L = self.W = 0
+        self.N = self.L = self.W = self.K = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -96,7 +96,7 @@ class Plan:
     __del__ = close
 
     def _set(self, N, L, wb):
-        self.N, self.L, self.W = N, L, len(wb) - 1
+        self.N, self.L, self.W, self.K = N, L, len(wb) - 1, 0
 
     def load_device(self, N, L, d_seq, d_r, wb, stream=0):
         wb = _wb(wb)
