@@ -88,3 +88,44 @@ def test_distance_matrix_matches_oracle(N, L, W, seed, theta):
             offdiag = ~np.eye(N, dtype=bool)
             assert np.all(got[offdiag].reshape(N, N - 1).min(axis=1) <= 1e-4), "row minimum was not subtracted"
     plan.close()
+
+
+def test_distance_measure_mirror_walks_a_chunk():
+    """relate_amd.DistanceMeasure driven the way AncesTreeBuilder::BuildTopology drives the reference's
+    (src/anc_builder.cpp:279-370): GetMatrix at the first SNP of a section, then advance + GetMatrix SNP by SNP,
+    across a section change.  Its incremental bookkeeping must agree with the closed form above, and every
+    matrix with the oracle."""
+    import torch
+    ra = _ra()
+    N, L, W, theta = 60, 260, 2, 0.001
+    seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=61, r_mode="flat")
+    rpos = np.concatenate([[0.0], np.cumsum(r / 2500.0)])
+    plan = ra.Plan(0, 1, 0)
+    plan.load_host(seq, r, wb)
+    plan.prepare(theta, theta, 0, N)
+    stones = torch.zeros(plan.out_bytes(), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    plan.paint(stones.data_ptr())
+    plan.timings()
+    R = ra.record_bytes(N)
+    host = stones.cpu().numpy().reshape(W, N, R)
+    d = ra.DistanceMeasure(plan, seq, rpos, stones)
+    checked = 0
+    for w in range(W):
+        lo, hi = int(wb[w]), int(wb[w + 1]) - 1
+        a_snp = ol.decode_records(host[w:w + 1])["a_snp"][0]
+        for snp in range(lo, hi + 1):
+            if snp > lo:
+                d.advance(snp)
+            got = d.GetMatrix(snp).cpu().numpy()
+            assert (d.section_startpos, d.section_endpos) == (lo, hi)
+            row, interp, wl, wr = bookkeeping(seq, rpos, wb, w, snp, a_snp, d.row_offsets)
+            g_row, g_interp, g_wl, g_wr = d._last_args
+            assert np.array_equal(g_row, row) and np.array_equal(g_interp, interp), f"snp {snp}"
+            assert np.allclose(g_wl, wl, rtol=1e-12, atol=0) and np.allclose(g_wr, wr, rtol=1e-12, atol=0)
+            if snp in (lo, lo + 1, (lo + hi) // 2, hi):
+                want = ol.distance_matrix(d.topology.cpu().numpy(), d.logscales.cpu().numpy(), row, interp, wl, wr, N)
+                assert np.all(np.abs(got - want) <= 1e-5 * np.maximum(1.0, np.abs(want)))
+                checked += 1
+    assert checked == 4 * W
+    plan.close()
