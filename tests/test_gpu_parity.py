@@ -89,9 +89,10 @@ def test_golden_vectors(name, variant, waves):
     g = load_golden(name)
     got = gpu_paint(g["seq"], g["r"], g["theta_painter"], g["theta_data"], g["wb"], variant, waves)
     frac = compare_records(got, g["stones"], g["N"], f"{name} v{variant} g{waves}")
-    # variant 0 rounds every operation as the reference does and differs only in the order of the sums;
-    # variant 1 also fuses / reassociates the backward update, so more last bits differ
-    assert frac < (1e-3 if variant == 0 else 0.2), f"{frac:.2e} of the floats are not bit-identical to the reference"
+    # the state is FP64 and the stones FP32: a different order of the sums (both variants) or a regrouped
+    # backward update (variant 1) moves a double by an ulp or so, which almost never survives the rounding to
+    # float -- measured: no stored float differs on any golden vector (tools/bit_identity.py)
+    assert frac < 1e-4, f"{frac:.2e} of the floats are not bit-identical to the reference"
 
 
 def test_entry_point_host_buffers_matches_golden():
@@ -120,7 +121,7 @@ def test_against_oracle(N, L, W, seed, mode, tp, td, waves):
     want = ol.oracle().paint_stones(seq, r, tp, td, wb)
     got = gpu_paint(seq, r, tp, td, wb, 1, waves)
     frac = compare_records(got, want, N, f"N={N} L={L}")
-    assert frac < 0.2
+    assert frac < 1e-4
 
 
 def test_full_size_sampled_targets_and_structure():
