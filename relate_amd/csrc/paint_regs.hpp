@@ -372,28 +372,32 @@ __device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, doub
   "v_mov_b32_dpp v[%[t]+1], v[%[x]+1] " ctrl " row_mask:0xf bank_mask:0xf\n\t"           \
   "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"
 
-// Sum over the 64 lanes of the value left in v[kX:kX+1], the same bits in every lane: four exchange
-// steps inside each 16-lane row, then the four row sums through SGPRs, added as (r0 + r1) + (r2 + r3).
-#define RELATE_WAVE_SUM_TAIL                                        \
-  RELATE_DPP_STEP("quad_perm:[1,0,3,2]")                            \
-  RELATE_DPP_STEP("quad_perm:[2,3,0,1]")                            \
-  RELATE_DPP_STEP("row_half_mirror")                                \
-  RELATE_DPP_STEP("row_mirror")                                     \
-  "s_nop 0\n\t"                                                     \
-  "v_readlane_b32 s[%[rl]+0], v[%[x]], 0\n\t"                       \
-  "v_readlane_b32 s[%[rl]+1], v[%[x]+1], 0\n\t"                     \
-  "v_readlane_b32 s[%[rl]+2], v[%[x]], 16\n\t"                      \
-  "v_readlane_b32 s[%[rl]+3], v[%[x]+1], 16\n\t"                    \
-  "v_readlane_b32 s[%[rl]+4], v[%[x]], 32\n\t"                      \
-  "v_readlane_b32 s[%[rl]+5], v[%[x]+1], 32\n\t"                    \
-  "v_readlane_b32 s[%[rl]+6], v[%[x]], 48\n\t"                      \
-  "v_readlane_b32 s[%[rl]+7], v[%[x]+1], 48\n\t"                    \
-  "s_nop 1\n\t"                                                     \
-  "v_mov_b64 v[%[t]:%[t]+1], s[%[rl]+2:%[rl]+3]\n\t"                \
-  "v_add_f64 v[%[t]:%[t]+1], s[%[rl]:%[rl]+1], v[%[t]:%[t]+1]\n\t"  \
-  "v_mov_b64 v[%[x]:%[x]+1], s[%[rl]+6:%[rl]+7]\n\t"                \
-  "v_add_f64 v[%[x]:%[x]+1], s[%[rl]+4:%[rl]+5], v[%[x]:%[x]+1]\n\t" \
-  "v_add_f64 %[out], v[%[t]:%[t]+1], v[%[x]:%[x]+1]"
+// Sum over the 64 lanes of the value left in v[kX:kX+1], the same bits in every lane of the result: four
+// exchange steps inside each 16-lane row, then the row sums travel down the wave (row_bcast 15: rows 1 and 3
+// take in rows 0 and 2; row_bcast 31: row 3 takes in row 1), i.e. (r3 + r2) + (r1 + r0), and lane 63 is read out.
+#define RELATE_WAVE_SUM_TAIL                                                                   \
+  RELATE_DPP_STEP("quad_perm:[1,0,3,2]")                                                       \
+  RELATE_DPP_STEP("quad_perm:[2,3,0,1]")                                                       \
+  RELATE_DPP_STEP("row_half_mirror")                                                           \
+  RELATE_DPP_STEP("row_mirror")                                                                \
+  "s_mov_b32 s[%[rl]+2], 0xffff0000\n\t"                                                       \
+  "s_mov_b32 s[%[rl]+3], 0xffff0000\n\t"                                                       \
+  "v_mov_b32_dpp v[%[t]], v[%[x]] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                 \
+  "v_mov_b32_dpp v[%[t]+1], v[%[x]+1] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"             \
+  "s_mov_b64 exec, s[%[rl]+2:%[rl]+3]\n\t"                                                     \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"                               \
+  "s_mov_b64 exec, -1\n\t"                                                                     \
+  "s_nop 0\n\t"                                                                                \
+  "v_mov_b32_dpp v[%[t]], v[%[x]] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                 \
+  "v_mov_b32_dpp v[%[t]+1], v[%[x]+1] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"             \
+  "s_mov_b32 exec_lo, 0\n\t"                                                                   \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"                               \
+  "s_mov_b64 exec, -1\n\t"                                                                     \
+  "s_nop 0\n\t"                                                                                \
+  "v_readlane_b32 s[%[rl]+0], v[%[x]], 63\n\t"                                                 \
+  "v_readlane_b32 s[%[rl]+1], v[%[x]+1], 63\n\t"                                               \
+  "s_nop 1\n\t"                                                                                \
+  "v_mov_b64 %[out], s[%[rl]:%[rl]+1]"
 
 // wave sum of x
 __device__ __forceinline__ double wave_sum_regs(double x)
