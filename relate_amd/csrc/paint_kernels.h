@@ -22,6 +22,8 @@ struct PaintConsts {
   double inv_theta_d;   // 1 / theta_d, 1 / ntheta_d (the register-resident kernel multiplies where the
   double inv_ntheta_d;  // reference divides, src/fast_painting.cpp:488-489)
   double lo, hi;        // rescale thresholds 1e-10, 1e10
+  int32_t same_theta;   // theta_painter == theta_data: the backward pass may run on one row per step
+  int32_t reserved;
 };
 
 // Per derived site j of a target, for the register-resident kernel: the two per-gap terms and the list

@@ -46,7 +46,7 @@ constexpr int kLo = kCV + 4;  // v[kLo:kLo+1] lower rescale threshold, v[kHi:kHi
 constexpr int kHi = kCV + 6;
 constexpr int kA0 = kCV + 8;  // v[kA0 + 2i : kA0 + 2i + 1] = state of word i
 constexpr int kBufA = kCS, kBufB = kCS + 8, kBufC = kCS + 16, kBufD = kCS + 24;  // 4 x 8 SGPRs of row words
-constexpr int kRL = kBufB;      // readlane results of the reduction (the B buffer is idle then)
+constexpr int kRL = kBufD;      // readlane results of the reduction (the D buffer is idle then in every schedule)
 constexpr int kCoefN = kCS + 32, kNxN = kCS + 34;  // prefetched per-gap terms (pairs; one 4-aligned quad)
 constexpr int kDkN = kCS + 36;  // prefetched list entry
 constexpr int kCnt = kCS + 37;  // loop counter of the padding-lane writes
@@ -147,6 +147,33 @@ __device__ __forceinline__ void scopy8()
       "s_mov_b64 s[%0+4:%0+5], s[%1+4:%1+5]\n\ts_mov_b64 s[%0+6:%0+7], s[%1+6:%1+7]" ::"n"(DST),
       "n"(SRC));
 }
+// NW (1..8) row words at p + OFF bytes -> s[SB..]: five or more travel as one 16-dword load.  The load
+// may fetch up to 3 words past the ones asked for (the packed rows are allocated with that slack).
+template <int SB, int OFF, int NW>
+__device__ __forceinline__ void sload_words(const uint64_t* p)
+{
+  static_assert(NW >= 1 && NW <= 8 && (SB == kBufA || SB == kBufC), "one half of the row-word registers");
+  if constexpr (NW > 4)
+    asm volatile("s_load_dwordx16 s[%1:%1+15], %0, %2" ::"s"(p), "n"(SB), "n"(OFF) : "memory");
+  else
+    sload4<SB, OFF>(p);
+}
+// The MPL words of a wave as an even number of batches of at most 8 words: batch b is fetched into
+// s[kBufA..] (b even) or s[kBufC..] (b odd) while batch b-1 is computed, and with an even count the
+// first batch of the next site lands in s[kBufA..] again.  Scalar loads return out of order, so the only
+// wait there is waits for all of them: the time to hide a fetch is the length of one batch, hence
+// batches as long as the registers allow.
+template <int MPL>
+struct RowBatches {
+  static constexpr int NB = ((MPL + 7) / 8 + 1) / 2 * 2;
+  static constexpr int size(int b) { return MPL / NB + (b < MPL % NB ? 1 : 0); }
+  static constexpr int first(int b)
+  {
+    int o = 0;
+    for (int i = 0; i < b; i++) o += size(i);
+    return o;
+  }
+};
 // The record of a list entry (SiteRec: coef, nx, dk_fwd2, dk_bwd2), fetched during a sweep for the site
 // after it.  The two list entries land in s[kDkN] (forward) and s[kCnt] (backward); the latter doubles
 // as the loop counter of write_stateless(), which has finished before the fetch is issued.
@@ -228,6 +255,22 @@ __device__ __forceinline__ void state_to_lds(uint32_t lds_addr)
                : "memory");
 }
 
+// float(state I * (inv_mis where the lane mismatches row word s[SW:SW+1] under sk, else inv_match)) -> LDS
+template <int I, int SW>
+__device__ __forceinline__ void state_unemitted_to_lds(uint32_t lds_addr, double inv_match, double inv_mis, uint64_t sk)
+{
+  asm volatile(
+      "v_mul_f64 v[%[t]:%[t]+1], v[%[a]:%[a]+1], %[im]\n\t"
+      "s_andn2_b64 exec, %[sk], s[%[w]:%[w]+1]\n\t"
+      "v_mul_f64 v[%[t]:%[t]+1], v[%[a]:%[a]+1], %[ix]\n\t"
+      "s_mov_b64 exec, -1\n\t"
+      "v_cvt_f32_f64 v[%[x]], v[%[t]:%[t]+1]\n\t"
+      "ds_write_b32 %[addr], v[%[x]] offset:%[off]" ::[addr] "v"(lds_addr),
+      [im] "v"(inv_match), [ix] "v"(inv_mis), [sk] "s"(sk), [a] "n"(kA0 + 2 * I), [t] "n"(kT), [x] "n"(kX + (I & 1)),
+      [w] "n"(SW), [off] "n"(256 * I)
+      : "memory", "scc");
+}
+
 // Lanes without a state <- -(x*y): the target's own lane (selfm = its bit, or 0 if its word belongs to
 // another wave; selfidx = 2 * local word) and every lane from the first padding lane of the wave on
 // (phm = lanes of that word, phidx = 2 * its local word; 2*MPL if the wave has none).  x*y is what the
@@ -295,11 +338,20 @@ __device__ __forceinline__ void fwd_batch(double& c0, double& c1, double rx, dou
                  RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2) RELATE_FWD_MUL(3)
                  "s_mov_b64 exec, -1\n\t"
                  RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_ACC(c1, 3) RELATE_FWD_OPS);
+  else if constexpr (NW == 3 && FIRST)
+    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2)
+                 RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2)
+                 "s_mov_b64 exec, -1\n\t"
+                 RELATE_FWD_SET(c0, 0) RELATE_FWD_SET(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_OPS);
   else if constexpr (NW == 3)
     asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2)
                  RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2)
                  "s_mov_b64 exec, -1\n\t"
                  RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_OPS);
+  else if constexpr (NW == 2 && FIRST)
+    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_MUL(0) RELATE_FWD_MUL(1)
+                 "s_mov_b64 exec, -1\n\t"
+                 RELATE_FWD_SET(c0, 0) RELATE_FWD_SET(c1, 1) RELATE_FWD_OPS);
   else if constexpr (NW == 2)
     asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_MUL(0) RELATE_FWD_MUL(1)
                  "s_mov_b64 exec, -1\n\t"
@@ -307,6 +359,31 @@ __device__ __forceinline__ void fwd_batch(double& c0, double& c1, double rx, dou
   else
     asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_MUL(0) "s_mov_b64 exec, -1\n\t" RELATE_FWD_ACC(c0, 0) RELATE_FWD_OPS);
 #undef RELATE_FWD_OPS
+}
+
+// One site of the one-row recursion, state' = (state + rx) * (mismatch ? rho : 1), over the MPL words of
+// the wave; c0 + c1 = sum of the new states.  The first batch of row `rp` is already on its way into
+// s[kBufA..]; the first batch of `rp_next` is requested during the last batch.
+template <int MPL>
+__device__ __forceinline__ void sweep_row(double& c0, double& c1, double rx, double rho, uint64_t sk, const uint64_t* rp,
+                                          const uint64_t* rp_next)
+{
+  using RB = RowBatches<MPL>;
+  static_for<0, RB::NB>([&](auto bc) __attribute__((always_inline)) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int cur = (b & 1) ? kBufC : kBufA;
+    constexpr int nxt = (b & 1) ? kBufA : kBufC;
+    constexpr int w0 = RB::first(b), nw = RB::size(b);
+    const uint64_t* rpl = rp;
+    const uint64_t* rpn = rp_next;
+    swait();
+    if constexpr (b + 1 < RB::NB) sload_words<nxt, 8 * RB::first(b + 1), RB::size(b + 1)>(rpl);
+    else sload_words<nxt, 0, RB::size(0)>(rpn);
+    const double rxl = rx, rhol = rho;
+    const uint64_t skl = sk;
+    fwd_batch<w0, cur, (nw > 4 ? 4 : nw), b == 0>(c0, c1, rxl, rhol, skl);
+    if constexpr (nw > 4) fwd_batch<w0 + 4, cur + 8, nw - 4, false>(c0, c1, rxl, rhol, skl);
+  });
 }
 
 #define RELATE_BWD_ADD(i) "v_add_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[aa]\n\t"
@@ -327,7 +404,7 @@ struct BwdAcc {
 template <int W0, int SN, int SC, int NW, bool FIRST>
 __device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, double aa, uint64_t skn, uint64_t skc)
 {
-  static_assert(!FIRST || NW >= 2, "the first batch initialises both accumulators");
+  static_assert(!FIRST || NW == 4, "the first batch of this schedule is a full one and initialises both accumulators");
 #define RELATE_BWD_OPS                                                                                         \
   : [ca0] "+v"(c.a0), [ca1] "+v"(c.a1), [cm0] "+v"(c.m0), [cm1] "+v"(c.m1)                                     \
   : [rho] "v"(rho), [c1] "v"(c1), [aa] "v"(aa), [skn] "s"(skn), [skc] "s"(skc), [r] "n"(kA0 + 2 * W0),        \
@@ -603,15 +680,15 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     };
     emit(0, 0);
     const Stateless z = stateless();
-    const double rho = ka.p.c.rho_theta;
+    double rho = ka.p.c.rho_theta;
+    asm volatile("" : "+v"(rho));  // stays in a vector register: re-reading it from the argument segment would add a wait to every site
     set_thresholds(ka.p.c.lo, ka.p.c.hi);
     int s_cur = __builtin_amdgcn_readfirstlane(dk[1]);  // nd >= 2: sites 0 and L-1 are always listed
     int s_next = __builtin_amdgcn_readfirstlane(dk[2 < nd ? 2 : nd - 1]);
     double coef_j = rec[0].coef, nx_j = rec[0].nx;  // terms of the gap before site j
     set_site_pointer(rec + 1);
     const uint64_t* rp = rows_w + (size_t)s_cur * stride;
-    sload4<kBufA, 0>(rp);
-    swait();
+    sload_words<kBufA, 0, RowBatches<MPL>::size(0)>(rp);
     for (int j = 1; j < nd; j++) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
       const double rx = S * coef_j;
@@ -622,23 +699,10 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       ls += nx_j;
       double c0, c1;
       const uint64_t* rp_next = rows_w + (size_t)s_next * stride;
-      static_for<0, NB>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int b = decltype(ic)::value;
-        constexpr int cur = (b & 1) ? kBufB : kBufA;
-        constexpr int nxt = (b & 1) ? kBufA : kBufB;
-        const uint64_t* rpl = rp;
-        const uint64_t* rpn = rp_next;
-        if constexpr (b + 1 < NB) sload4<nxt, (b + 1) * 32>(rpl);
-        else sload4<nxt, 0>(rpn);
-        const double rxl = rx, rhol = rho;
-        const uint64_t skl = skm;
-        fwd_batch<4 * b, cur, (b + 1 < NB ? 4 : LASTW), b == 0>(c0, c1, rxl, rhol, skl);
-        swait();
-      });
-      if constexpr (NB & 1) scopy8<kBufA, kBufB>();
+      sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
       S = block_sum_regs<G>(red, slot, c0, c1);
       int s_next2;
-      fetched_site<true>(s_next2, coef_j, nx_j);
+      fetched_site<true>(s_next2, coef_j, nx_j);  // arrived: every batch but the first has waited since the fetch
       if (out_of_range(S)) {
         const double inv = 1.0 / S;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
@@ -653,9 +717,120 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       s_next = s_next2;
       rp = rp_next;
     }
+    swait();
   }
 
-  // ---------------- backward (src/fast_painting.cpp:410-599) ----------------
+  // ---------------- backward, one emission probability (src/fast_painting.cpp:410-599) ----------------
+  // The reference keeps beta and weights it with the emission of the current site when it sums
+  // (:509-517), which takes the masks of two rows per step.  When the painter and the data hold the same
+  // theta (FastPainting(Data&), src/fast_painting.hpp:32-45) the emission-weighted state g = beta * e obeys
+  // the forward recursion, g' = (g + rx) * (mismatch' ? rho : 1) with B = sum g, on the masks of one row;
+  // beta itself is needed at the stones only, as g / e.
+  else if (ka.p.c.same_theta) {
+    const double theta_d = ka.p.c.theta_d, ntheta_d = ka.p.c.ntheta_d;
+    double ls = ka.p.c.log_Nm1 - (double)nd * ka.p.c.log_ntheta;
+    const uint64_t* row_last = rows_w + (size_t)(ka.p.L - 1) * stride;
+    double acc = 0.0;
+    static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      const int wi = wbase + i;
+      const uint64_t w = row_last[i];
+      const bool v = __builtin_amdgcn_inverse_ballot_w64(valid_mask(wi, ka.p.N, k));
+      const bool m = __builtin_amdgcn_inverse_ballot_w64(~w & sk_last);
+      const double g = v ? (m ? theta_d : ntheta_d) : 0.0;
+      state_set<i>(g);
+      acc += g;
+    });
+    double B = block_sum_regs<G>(red, slot, acc);
+    int wcur = ka.p.W - 1;
+    int stone_j = nd - 1;  // the last window ends at the last SNP
+    // stones taken at the last SNP hold beta = 1 for every state, the target included (:427-432,:447-462)
+    while (stone_j == nd - 1) {
+      KArgsPtr q = rare_args();
+      const int N = q->p.N;
+      uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
+      if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, q->p.L - 1, (float)ls);
+      float* dst = reinterpret_cast<float*>(rec + 56 + (size_t)4 * N);
+      for (int n = threadIdx.x; n < N; n += 64 * G) dst[n] = 1.0f;
+      wcur--;
+      stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
+    }
+    const Stateless z = stateless();
+    double rho = ka.p.c.rho_theta;
+    asm volatile("" : "+v"(rho));
+    set_thresholds(ka.p.c.lo, ka.p.c.hi);
+    int s_cur = __builtin_amdgcn_readfirstlane(dk[nd - 2]);
+    int s_prev = __builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]);
+    double coef_j = rec[nd - 1].coef, nx_j = rec[nd - 1].nx;  // terms used by the step to site j: index j + 1
+    set_site_pointer(rec + (nd - 2));
+    const uint64_t* rp = rows_w + (size_t)s_cur * stride;
+    sload_words<kBufA, 0, RowBatches<MPL>::size(0)>(rp);
+    for (int j = nd - 2; j >= 0; j--) {
+      if ((j & 31) == 0) rotate_priority(rank, j, 0);
+      const double rx = B * coef_j;
+      write_stateless<MPL>(B, coef_j, z.selfm, z.selfidx, z.phm, z.phidx);
+      // scalars of the step to site j-1 travel during this sweep
+      prefetch_site<false>();
+      const uint64_t skm = edge_select(j, 0, sk_first);
+      ls += nx_j;
+      double c0, c1;
+      const uint64_t* rp_next = rows_w + (size_t)s_prev * stride;
+      sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
+      B = block_sum_regs<G>(red, slot, c0, c1);
+      int s_prev2;
+      fetched_site<false>(s_prev2, coef_j, nx_j);
+      if (out_of_range(B)) {
+        const double inv = 1.0 / B;
+        static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
+          const double f = inv;
+          state_scale<decltype(ic)::value>(f);
+        });
+        ls += (double)fast_log_dev((float)B);  // float approximation on this side (:562)
+        B = 1.0;
+      }
+      while (stone_j == j) {
+        KArgsPtr q = rare_args();
+        const int N = q->p.N;
+        uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
+        if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, s_cur, (float)ls);
+        // beta = g / emission of this site; the row words are fetched again (the registers hold the next row's by now)
+        {
+          using RB = RowBatches<MPL>;
+          const double inv_match = q->p.c.inv_ntheta_d, inv_mis = q->p.c.inv_theta_d;
+          swait();
+          static_for<0, RB::NB>([&](auto bc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value;
+            constexpr int w0 = RB::first(b), nw = RB::size(b);
+            const uint64_t* rpl = rp;
+            sload_words<kBufA, 8 * w0, nw>(rpl);
+            swait();
+            static_for<0, nw>([&](auto ic) __attribute__((always_inline)) {
+              constexpr int i = decltype(ic)::value;
+              const double im = inv_match, ix = inv_mis;
+              const uint64_t skl = skm;
+              const uint32_t al = lds_mine;
+              state_unemitted_to_lds<w0 + i, kBufA + 2 * i>(al, im, ix, skl);
+            });
+          });
+          swait();
+          __syncthreads();
+          float* dst = reinterpret_cast<float*>(rec + 56 + (size_t)4 * N);
+          for (int n = threadIdx.x; n < N; n += 64 * G) dst[n] = stage[n];
+          __syncthreads();
+          const uint64_t* rpn = rp_next;
+          sload_words<kBufA, 0, RB::size(0)>(rpn);  // what the next sweep expects there
+        }
+        wcur--;
+        stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
+      }
+      s_cur = s_prev;
+      s_prev = s_prev2;
+      rp = rp_next;
+    }
+    swait();
+  }
+
+  // ---------------- backward, two emission probabilities (FastPainting(N, theta) beside Data::theta) ----------------
   else {
     const double theta_d = ka.p.c.theta_d, ntheta_d = ka.p.c.ntheta_d;
     double ls = ka.p.c.log_Nm1 - (double)nd * ka.p.c.log_ntheta;

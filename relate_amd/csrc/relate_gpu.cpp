@@ -95,6 +95,8 @@ relate::PaintConsts make_consts(int N, double theta_p, double theta_d)
   c.inv_ntheta_d = 1.0 / c.ntheta_d;
   c.lo = 1e-10;
   c.hi = 1.0 / c.lo;
+  c.same_theta = theta_p == theta_d ? 1 : 0;
+  c.reserved = 0;
   return c;
 }
 

@@ -157,6 +157,29 @@ __global__ void k(double* out, const uint64_t* masks, int iters, long long* cyc)
           : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(m0), "+v"(m1)
           : "v"(rx), "v"(rho), "s"(sm0), "s"(sm1), "s"(sm1) : "scc");
       a4 += (c0 + c1 + m0 + m1) * 1e-30;
+    } else if constexpr (P == 20) {  // 8 independent FP64 MFMAs (4 blocks of 4x4x4)
+      asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %8, %9, %0\n v_mfma_f64_4x4x4_4b_f64 %1, %8, %9, %1\n v_mfma_f64_4x4x4_4b_f64 %2, %8, %9, %2\n"
+                   "v_mfma_f64_4x4x4_4b_f64 %3, %8, %9, %3\n v_mfma_f64_4x4x4_4b_f64 %4, %8, %9, %4\n v_mfma_f64_4x4x4_4b_f64 %5, %8, %9, %5\n"
+                   "v_mfma_f64_4x4x4_4b_f64 %6, %8, %9, %6\n v_mfma_f64_4x4x4_4b_f64 %7, %8, %9, %7\n s_nop 7\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(rx), "v"(rho));
+    } else if constexpr (P == 21) {  // 1 MFMA + 7 independent v_add_f64
+      asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %8, %9, %0\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+                   "v_add_f64 %4, %4, %8\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(rx), "v"(rho));
+    } else if constexpr (P == 22) {  // 2 MFMA + 6 independent v_add_f64
+      asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %8, %9, %0\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n v_add_f64 %3, %3, %8\n"
+                   "v_mfma_f64_4x4x4_4b_f64 %4, %8, %9, %4\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(rx), "v"(rho));
+    } else if constexpr (P == 23) {  // a chain of 3 dependent MFMAs (the reduction) + 7 independent v_add_f64 spread between them
+      asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %0, %9, 0\n v_add_f64 %1, %1, %8\n v_add_f64 %2, %2, %8\n s_nop 3\n"
+                   "v_mfma_f64_4x4x4_4b_f64 %0, %0, %9, 0\n v_add_f64 %3, %3, %8\n v_add_f64 %4, %4, %8\n s_nop 3\n"
+                   "v_mfma_f64_4x4x4_4b_f64 %0, %0, %9, 0\n v_add_f64 %5, %5, %8\n v_add_f64 %6, %6, %8\n v_add_f64 %7, %7, %8\n s_nop 2\n"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(rx), "v"(rho));
+    } else if constexpr (P == 24) {  // the same chain alone
+      asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %0, %2, 0\n s_nop 5\n"
+                   "v_mfma_f64_4x4x4_4b_f64 %0, %0, %2, 0\n s_nop 5\n"
+                   "v_mfma_f64_4x4x4_4b_f64 %0, %0, %2, 0\n s_nop 5\n"
+                   : "+v"(a0) : "v"(rx), "v"(rho));
     } else if constexpr (P == 9) {  // 8 v_cndmask_b32 with SGPR mask
       asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
                    "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n"
@@ -165,6 +188,44 @@ __global__ void k(double* out, const uint64_t* masks, int iters, long long* cyc)
   }
   if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = clock64() - t_start;
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7;
+}
+
+// Which input lanes reach which output lane of one 4-block 4x4x4 FP64 MFMA when the other operand is all ones:
+// reach[(side*64 + p)*64 + lane] = output of lane `lane` for the one-hot input at lane p (side 0: data as A, 1: as B).
+__global__ void mfma_layout(double* reach)
+{
+  const int lane = threadIdx.x;
+  for (int side = 0; side < 2; side++)
+    for (int p = 0; p < 64; p++) {
+      const double hot = lane == p ? 1.0 : 0.0;
+      const double d = side == 0 ? __builtin_amdgcn_mfma_f64_4x4x4f64(hot, 1.0, 0.0, 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, hot, 0.0, 0, 0, 0);
+      reach[(side * 64 + p) * 64 + lane] = d;
+    }
+}
+
+static void layout_report()
+{
+  double* d; hipMalloc(&d, 2 * 64 * 64 * 8);
+  hipLaunchKernelGGL(mfma_layout, dim3(1), dim3(64), 0, 0, d);
+  std::vector<double> h(2 * 64 * 64);
+  hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  for (int side = 0; side < 2; side++) {
+    printf("mfma_f64_4x4x4 layout, data as %s, other operand ones: output lane <- input lanes\n", side ? "B" : "A");
+    for (int lane = 0; lane < 64; lane++) {
+      printf("  out %2d <-", lane);
+      for (int p = 0; p < 64; p++) if (h[(side * 64 + p) * 64 + lane] != 0.0) printf(" %d", p);
+      printf("\n");
+    }
+    // three applications: count of each input lane in every output lane
+    std::vector<double> m(64 * 64), t(64 * 64), u(64 * 64);
+    for (int o = 0; o < 64; o++) for (int p = 0; p < 64; p++) m[o * 64 + p] = h[(side * 64 + p) * 64 + o];
+    auto mul = [](const std::vector<double>& x, const std::vector<double>& y, std::vector<double>& z) {
+      for (int i = 0; i < 64; i++) for (int j = 0; j < 64; j++) { double s = 0; for (int q = 0; q < 64; q++) s += x[i * 64 + q] * y[q * 64 + j]; z[i * 64 + j] = s; } };
+    mul(m, m, t); mul(m, t, u);
+    for (int o : {0, 1, 4, 16, 63}) { printf("  after 3 applications, out %2d counts:", o); for (int p = 0; p < 64; p++) printf(" %g", u[o * 64 + p]); printf("\n"); }
+  }
+  hipFree(d);
 }
 
 template <int P>
@@ -203,6 +264,12 @@ int main()
   hipMalloc(&d_masks, 16);
   uint64_t h[2] = {0x5555aaaa3333ccccull, 0x0f0ff0f012345678ull};
   hipMemcpy(d_masks, h, 16, hipMemcpyHostToDevice);
+  layout_report();
+  run<20>("mfma_f64_4x4x4 x8 indep", 8, d_out, d_masks);
+  run<21>("1 mfma + 7 v_add_f64", 8, d_out, d_masks);
+  run<22>("2 mfma + 6 v_add_f64", 8, d_out, d_masks);
+  run<23>("3-mfma chain + 7 v_add_f64", 10, d_out, d_masks);
+  run<24>("3-mfma chain alone", 3, d_out, d_masks);
   run<1>("v_add_f64 x8 indep", 8, d_out, d_masks);
   run<2>("v_fma_f64 x8 indep", 8, d_out, d_masks);
   run<3>("v_mul_f64 x8 indep", 8, d_out, d_masks);
