@@ -7,6 +7,9 @@
 
 namespace relate {
 
+// Rescale thresholds of the recursions: kRescaleLo and its reciprocal (src/fast_painting.hpp:20-21).
+constexpr double kRescaleLo = 1e-10;
+
 // Constants of one painter, computed on the host with the host's libm exactly
 // as the reference's constructors do (src/fast_painting.hpp:19-45).
 struct PaintConsts {

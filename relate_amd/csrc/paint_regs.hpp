@@ -33,9 +33,9 @@ using namespace dev;
 
 // ---- register map -------------------------------------------------------------------------------
 #define RELATE_CV 48  // compiler: v0..v47
-#define RELATE_CS 60  // compiler: s0..s59
-// amdgpu_num_sgpr counts the 8 special registers (VCC, FLAT_SCRATCH, XNACK_MASK) on top of s0..s59
-#define RELATE_CS_ATTR 68
+#define RELATE_CS 52  // compiler: s0..s51
+// amdgpu_num_sgpr counts the 8 special registers (VCC, FLAT_SCRATCH, XNACK_MASK) on top of s0..s51
+#define RELATE_CS_ATTR 60
 // amdgpu_num_vgpr is doubled by the gfx90a+ back end (unified VGPR/AGPR file); no AGPRs are used here
 #define RELATE_CV_ATTR 24
 constexpr int kCV = RELATE_CV, kCS = RELATE_CS;
@@ -45,14 +45,22 @@ constexpr int kT = kCV + 2;   // v[kT:kT+1]   scratch pair
 constexpr int kLo = kCV + 4;  // v[kLo:kLo+1] lower rescale threshold, v[kHi:kHi+1] upper
 constexpr int kHi = kCV + 6;
 constexpr int kA0 = kCV + 8;  // v[kA0 + 2i : kA0 + 2i + 1] = state of word i
-constexpr int kBufA = kCS, kBufB = kCS + 8, kBufC = kCS + 16, kBufD = kCS + 24;  // 4 x 8 SGPRs of row words
+// Values that every site of a pass reads and none writes: held here, the compiler cannot decide to park
+// them in VGPR lanes and fetch them back (v_readlane, a vector instruction) at every site.
+constexpr int kRowsW = kCS;        // s[kRowsW:kRowsW+1] first row word of this wave (row 0)
+constexpr int kSelfIdx = kCS + 2;  // 2 * local word of the target's own lane
+constexpr int kPhIdx = kCS + 3;    // 2 * local word of the first padding lane (2*MPL: none)
+constexpr int kSelfM = kCS + 4;    // s[kSelfM:kSelfM+1] the target's own lane (0: another wave has it)
+constexpr int kPhM = kCS + 6;      // s[kPhM:kPhM+1] padding lanes of word kPhIdx/2
+constexpr int kBufA = kCS + 8, kBufB = kCS + 16, kBufC = kCS + 24, kBufD = kCS + 32;  // 4 x 8 SGPRs of row words
 constexpr int kRL = kBufD;      // readlane results of the reduction (the D buffer is idle then in every schedule)
-constexpr int kCoefN = kCS + 32, kNxN = kCS + 34;  // prefetched per-gap terms (pairs; one 4-aligned quad)
-constexpr int kDkN = kCS + 36;  // prefetched list entry
-constexpr int kCnt = kCS + 37;  // loop counter of the padding-lane writes
-constexpr int kRec = kCS + 38;  // s[kRec:kRec+1] running pointer into the site records
+constexpr int kCoefN = kCS + 40, kNxN = kCS + 42;  // prefetched per-gap terms (pairs; one 4-aligned quad)
+constexpr int kDkN = kCS + 44;  // prefetched list entry
+constexpr int kCnt = kCS + 45;  // loop counter of the padding-lane writes
+constexpr int kRec = kCS + 46;  // s[kRec:kRec+1] running pointer into the site records
+constexpr int kSkEdge = kCS + 48;  // s[kSkEdge:kSkEdge+1] the target's own allele at the forced end site of the pass, as a mask
 constexpr int kMaxMPL = (256 - kA0) / 2;
-static_assert(kRec + 1 <= 101 && kCoefN % 4 == 0 && kBufA % 4 == 0, "SGPR map");
+static_assert(kSkEdge + 1 <= 101 && kCoefN % 4 == 0 && kBufA % 4 == 0, "SGPR map");
 
 #define RELATE_REGS_ATTR __attribute__((amdgpu_num_vgpr(RELATE_CV_ATTR), amdgpu_num_sgpr(RELATE_CS_ATTR)))
 
@@ -68,7 +76,7 @@ __device__ __forceinline__ void static_for(F&& f)
 // Tells the compiler which registers the asm statements use by number: it then counts them in the
 // kernel's register budget and keeps its own SGPR-spill lanes out of them (the spill VGPRs are taken
 // from the registers it believes unused, whatever amdgpu_num_vgpr says).  Clobber names must be
-// literals, hence the cumulative lists: RELATE_VCLOB_<MPL> = v48 .. v[kA0 + 2*MPL - 1], RELATE_SCLOB = s60 .. s101.
+// literals, hence the cumulative lists: RELATE_VCLOB_<MPL> = v48 .. v[kA0 + 2*MPL - 1], RELATE_SCLOB = s52 .. s101.
 #define RELATE_VCLOB_4 "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
 #define RELATE_VCLOB_8 RELATE_VCLOB_4, "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71"
 #define RELATE_VCLOB_12 RELATE_VCLOB_8, "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
@@ -84,7 +92,7 @@ __device__ __forceinline__ void static_for(F&& f)
 #define RELATE_VCLOB_64 RELATE_VCLOB_56, "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183"
 #define RELATE_VCLOB_72 RELATE_VCLOB_64, "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199"
 #define RELATE_VCLOB_80 RELATE_VCLOB_72, "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"
-#define RELATE_SCLOB "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101"
+#define RELATE_SCLOB "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101"
 template <int MPL>
 __device__ __forceinline__ void claim_registers();
 #define RELATE_CLAIM(M)                                                \
@@ -109,7 +117,7 @@ RELATE_CLAIM(64)
 RELATE_CLAIM(72)
 RELATE_CLAIM(80)
 #undef RELATE_CLAIM
-static_assert(kCV == 48 && kA0 == 56 && kCS == 60, "the clobber lists above are written for this register map (tools/gen_clobbers.py 48 56 60)");
+static_assert(kCV == 48 && kA0 == 56 && kCS == 52, "the clobber lists above are written for this register map (tools/gen_clobbers.py 48 56 52)");
 
 // A wave-uniform value as an SGPR (the compiler's readfirstlane may be folded into a VGPR copy).
 __device__ __forceinline__ uint32_t sgpr32(uint32_t x)
@@ -123,12 +131,37 @@ __device__ __forceinline__ uint64_t sgpr64(uint64_t x)
   const uint32_t lo = sgpr32((uint32_t)x), hi = sgpr32((uint32_t)(x >> 32));
   return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ double sgpr_f64(double x) { return __longlong_as_double((long long)sgpr64((uint64_t)__double_as_longlong(x))); }
 // (j == j_edge) ? edge_mask : all ones, on the scalar unit.
 __device__ __forceinline__ uint64_t edge_select(int j, int j_edge, uint64_t edge_mask)
 {
   uint64_t r;
   asm volatile("s_cmp_eq_u32 %1, %2\n\ts_cselect_b64 %0, %3, -1" : "=s"(r) : "s"(j), "s"(j_edge), "s"(edge_mask) : "scc");
   return r;
+}
+
+// The same with the mask held in s[kSkEdge:kSkEdge+1] (set_edge_mask).
+__device__ __forceinline__ void set_edge_mask(uint64_t m) { asm volatile("s_mov_b64 s[%1:%1+1], %0" ::"s"(m), "n"(kSkEdge)); }
+__device__ __forceinline__ uint64_t edge_mask(int j, int j_edge)
+{
+  uint64_t r;
+  asm volatile("s_cmp_eq_u32 %1, %2\n\ts_cselect_b64 %0, s[%3:%3+1], -1" : "=s"(r) : "s"(j), "s"(j_edge), "n"(kSkEdge) : "scc");
+  return r;
+}
+// First row word of this wave in row `site`: s[kRowsW:kRowsW+1] + site * stride_bytes (set_rows_base).
+__device__ __forceinline__ void set_rows_base(const uint64_t* p) { asm volatile("s_mov_b64 s[%1:%1+1], %0" ::"s"(p), "n"(kRowsW)); }
+__device__ __forceinline__ const uint64_t* row_pointer(int site, uint32_t stride_bytes)
+{
+  uint32_t lo, hi;
+  asm volatile(
+      "s_mul_hi_u32 %1, %2, %3\n\t"
+      "s_mul_i32 %0, %2, %3\n\t"
+      "s_add_u32 %0, %0, s[%4]\n\t"
+      "s_addc_u32 %1, %1, s[%4+1]"
+      : "=&s"(lo), "=&s"(hi)
+      : "s"(site), "s"(stride_bytes), "n"(kRowsW)
+      : "scc");
+  return reinterpret_cast<const uint64_t*>(((uint64_t)hi << 32) | lo);
 }
 
 // ---- row words -------------------------------------------------------------------------------------
@@ -220,6 +253,21 @@ __device__ __forceinline__ bool out_of_range(double S)
       : "vcc", "scc");
   return m != 0;
 }
+// High word of the sum that block_sum_regs just returned.  With one wave per target it is still in the
+// scalar register the reduction read it into.
+template <int G>
+__device__ __forceinline__ uint32_t sum_high_word(double S)
+{
+  uint32_t h;
+  if constexpr (G == 1) asm volatile("s_mov_b32 %0, s[%1+1]" : "=s"(h) : "n"(kRL));
+  else h = sgpr32((uint32_t)__double2hiint(S));
+  return h;
+}
+// A sum in [2^-33, 2^33) lies strictly inside the rescale thresholds (kRescaleLo = 1e-10 and its reciprocal):
+// one scalar compare on the high word settles nearly every site; the rest (NaN and negative values included)
+// takes the exact comparison.
+static_assert(kRescaleLo < 0x1p-33 && 1.0 / kRescaleLo > 0x1p33, "band of the scalar range check");
+__device__ __forceinline__ bool surely_in_range(uint32_t high_word) { return high_word - 0x3DE00000u < 0x42000000u - 0x3DE00000u; }
 template <bool FWD>
 __device__ __forceinline__ void fetched_site(int& s, double& coef, double& nx)
 {
@@ -271,43 +319,59 @@ __device__ __forceinline__ void state_unemitted_to_lds(uint32_t lds_addr, double
       : "memory", "scc");
 }
 
-// Lanes without a state <- -(x*y): the target's own lane (selfm = its bit, or 0 if its word belongs to
-// another wave; selfidx = 2 * local word) and every lane from the first padding lane of the wave on
-// (phm = lanes of that word, phidx = 2 * its local word; 2*MPL if the wave has none).  x*y is what the
+// Lanes without a state <- -(x*y): the target's own lane (s[kSelfM..] = its bit, or 0 if its word belongs to
+// another wave; s[kSelfIdx] = 2 * local word) and every lane from the first padding lane of the wave on
+// (s[kPhM..] = lanes of that word, s[kPhIdx] = 2 * its local word; 2*MPL if the wave has none).  x*y is what the
 // sweep adds to these lanes (the product rounds like the caller's own x*y, so the sum is an exact zero).
-template <int MPL>
-__device__ __forceinline__ void write_stateless(double x, double y, uint64_t selfm, uint32_t selfidx, uint64_t phm,
-                                                uint32_t phidx)
+__device__ __forceinline__ void set_stateless(uint64_t selfm, uint32_t selfidx, uint64_t phm, uint32_t phidx)
 {
   asm volatile(
-      "v_mul_f64 v[%[t]:%[t]+1], %[x], -%[y]\n\t"
-      "s_mov_b64 exec, %[selfm]\n\t"
-      "s_set_gpr_idx_on %[selfidx], 8\n\t"
-      "s_nop 1\n\t"
-      "v_mov_b32 v[%[a0]], v[%[t]]\n\t"
-      "v_mov_b32 v[%[a0]+1], v[%[t]+1]\n\t"
-      "s_set_gpr_idx_off\n\t"
-      "s_mov_b32 s[%[cnt]], %[phidx]\n\t"
-      "s_mov_b64 exec, %[phm]\n\t"
-      "s_cmp_ge_u32 s[%[cnt]], %[end]\n\t"
-      "s_cbranch_scc1 .Lws_done%=\n"
-      ".Lws_loop%=:\n\t"
-      "s_set_gpr_idx_on s[%[cnt]], 8\n\t"
-      "s_nop 1\n\t"
-      "v_mov_b32 v[%[a0]], v[%[t]]\n\t"
-      "v_mov_b32 v[%[a0]+1], v[%[t]+1]\n\t"
-      "s_set_gpr_idx_off\n\t"
-      "s_mov_b64 exec, -1\n\t"
-      "s_add_u32 s[%[cnt]], s[%[cnt]], 2\n\t"
-      "s_cmp_lt_u32 s[%[cnt]], %[end]\n\t"
-      "s_cbranch_scc1 .Lws_loop%=\n"
-      ".Lws_done%=:\n\t"
-      "s_mov_b64 exec, -1"
-      :
-      : [x] "v"(x), [y] "v"(y), [selfm] "s"(selfm), [selfidx] "s"(selfidx), [phm] "s"(phm), [phidx] "s"(phidx), [t] "n"(kT),
-        [a0] "n"(kA0), [cnt] "n"(kCnt), [end] "n"(2 * MPL)
-      : "scc", "memory");
+      "s_mov_b64 s[%4:%4+1], %0\n\ts_mov_b32 s[%5], %1\n\ts_mov_b64 s[%6:%6+1], %2\n\ts_mov_b32 s[%7], %3" ::"s"(selfm),
+      "s"(selfidx), "s"(phm), "s"(phidx), "n"(kSelfM), "n"(kSelfIdx), "n"(kPhM), "n"(kPhIdx));
 }
+#define RELATE_WRITE_STATELESS_BODY                       \
+  "s_mov_b64 exec, s[%[selfm]:%[selfm]+1]\n\t"            \
+  "s_set_gpr_idx_on s[%[selfidx]], 8\n\t"                 \
+  "s_nop 1\n\t"                                           \
+  "v_mov_b32 v[%[a0]], v[%[t]]\n\t"                       \
+  "v_mov_b32 v[%[a0]+1], v[%[t]+1]\n\t"                   \
+  "s_set_gpr_idx_off\n\t"                                 \
+  "s_mov_b32 s[%[cnt]], s[%[phidx]]\n\t"                  \
+  "s_mov_b64 exec, s[%[phm]:%[phm]+1]\n\t"                \
+  "s_cmp_ge_u32 s[%[cnt]], %[end]\n\t"                    \
+  "s_cbranch_scc1 .Lws_done%=\n"                          \
+  ".Lws_loop%=:\n\t"                                      \
+  "s_set_gpr_idx_on s[%[cnt]], 8\n\t"                     \
+  "s_nop 1\n\t"                                           \
+  "v_mov_b32 v[%[a0]], v[%[t]]\n\t"                       \
+  "v_mov_b32 v[%[a0]+1], v[%[t]+1]\n\t"                   \
+  "s_set_gpr_idx_off\n\t"                                 \
+  "s_mov_b64 exec, -1\n\t"                                \
+  "s_add_u32 s[%[cnt]], s[%[cnt]], 2\n\t"                 \
+  "s_cmp_lt_u32 s[%[cnt]], %[end]\n\t"                    \
+  "s_cbranch_scc1 .Lws_loop%=\n"                          \
+  ".Lws_done%=:\n\t"                                      \
+  "s_mov_b64 exec, -1"
+#define RELATE_WRITE_STATELESS_REGS                                                                              \
+  [selfm] "n"(kSelfM), [selfidx] "n"(kSelfIdx), [phm] "n"(kPhM), [phidx] "n"(kPhIdx), [t] "n"(kT), [a0] "n"(kA0), \
+      [cnt] "n"(kCnt), [end] "n"(2 * MPL)
+// YS: y is wave-uniform and comes from a scalar register (no copy into a vector register)
+template <int MPL, bool YS>
+__device__ __forceinline__ void write_stateless(double x, double y)
+{
+  if constexpr (YS)
+    asm volatile("v_mul_f64 v[%[t]:%[t]+1], %[x], -%[y]\n\t" RELATE_WRITE_STATELESS_BODY
+                 :
+                 : [x] "v"(x), [y] "s"(y), RELATE_WRITE_STATELESS_REGS
+                 : "scc", "memory");
+  else
+    asm volatile("v_mul_f64 v[%[t]:%[t]+1], %[x], -%[y]\n\t" RELATE_WRITE_STATELESS_BODY
+                 :
+                 : [x] "v"(x), [y] "v"(y), RELATE_WRITE_STATELESS_REGS
+                 : "scc", "memory");
+}
+#undef RELATE_WRITE_STATELESS_BODY
+#undef RELATE_WRITE_STATELESS_REGS
 
 // ---- sweeps ----------------------------------------------------------------------------------------
 #define RELATE_A(i) "v[%[r]+" #i "*2:%[r]+" #i "*2+1]"
@@ -317,6 +381,7 @@ __device__ __forceinline__ void write_stateless(double x, double y, uint64_t sel
 #define RELATE_FWD_MUL(i) "s_andn2_b64 exec, %[sk], " RELATE_W(s, i) "\n\tv_mul_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[rho]\n\t"
 #define RELATE_FWD_ACC(c, i) "v_add_f64 %[" #c "], %[" #c "], " RELATE_A(i) "\n\t"
 #define RELATE_FWD_SET(c, i) "v_mov_b64 %[" #c "], " RELATE_A(i) "\n\t"
+#define RELATE_FWD_SUM2(c, i, k) "v_add_f64 %[" #c "], " RELATE_A(i) ", " RELATE_A(k) "\n\t"
 
 // forward sweep over NW (1..4) words: states kA0+2*W0.., row words in s[SB..]; the sums of the new
 // states go to two accumulators, which the first batch of a site initialises (FIRST)
@@ -332,7 +397,7 @@ __device__ __forceinline__ void fwd_batch(double& c0, double& c1, double rx, dou
     asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2) RELATE_FWD_ADD(3)
                  RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2) RELATE_FWD_MUL(3)
                  "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_SET(c0, 0) RELATE_FWD_SET(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_ACC(c1, 3) RELATE_FWD_OPS);
+                 RELATE_FWD_SUM2(c0, 0, 2) RELATE_FWD_SUM2(c1, 1, 3) RELATE_FWD_OPS);
   else if constexpr (NW == 4)
     asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2) RELATE_FWD_ADD(3)
                  RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2) RELATE_FWD_MUL(3)
@@ -342,7 +407,7 @@ __device__ __forceinline__ void fwd_batch(double& c0, double& c1, double rx, dou
     asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2)
                  RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2)
                  "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_SET(c0, 0) RELATE_FWD_SET(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_OPS);
+                 RELATE_FWD_SUM2(c0, 0, 2) RELATE_FWD_SET(c1, 1) RELATE_FWD_OPS);
   else if constexpr (NW == 3)
     asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2)
                  RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2)
@@ -390,7 +455,7 @@ __device__ __forceinline__ void sweep_row(double& c0, double& c1, double rx, dou
 #define RELATE_BWD_FMA(i) \
   "s_andn2_b64 exec, %[skn], " RELATE_W(sn, i) "\n\tv_fma_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[rho], %[c1]\n\t"
 #define RELATE_BWD_ALL(c, i) "v_add_f64 %[" #c "], %[" #c "], " RELATE_A(i) "\n\t"
-#define RELATE_BWD_SET(c, i) "v_mov_b64 %[" #c "], " RELATE_A(i) "\n\t"
+#define RELATE_BWD_SUM2(c, i, k) "v_add_f64 %[" #c "], " RELATE_A(i) ", " RELATE_A(k) "\n\t"
 #define RELATE_BWD_MIS(c, i) \
   "s_andn2_b64 exec, %[skc], " RELATE_W(sc, i) "\n\tv_add_f64 %[" #c "], %[" #c "], " RELATE_A(i) "\n\t"
 
@@ -414,7 +479,7 @@ __device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, doub
     asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2) RELATE_BWD_ADD(3)
                  RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3)
                  "s_mov_b64 exec, -1\n\t"
-                 RELATE_BWD_SET(ca0, 0) RELATE_BWD_SET(ca1, 1) RELATE_BWD_ALL(ca0, 2) RELATE_BWD_ALL(ca1, 3)
+                 RELATE_BWD_SUM2(ca0, 0, 2) RELATE_BWD_SUM2(ca1, 1, 3)
                  RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2) RELATE_BWD_MIS(cm1, 3)
                  "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
   else if constexpr (NW == 4)
@@ -578,11 +643,15 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
   constexpr int NB = (MPL + 3) / 4;  // 4-word batches per wave and site
   constexpr int LASTW = MPL - 4 * (NB - 1);
   // Dynamic LDS (sized by the launcher): with a static allocation the compiler derives an occupancy
-  // bound from it and then ignores amdgpu_num_sgpr.  Two rows of G partial sums, then the staging
-  // buffer of one stone payload (G * MPL * 64 floats).
+  // bound from it and then ignores amdgpu_num_sgpr.  Two rows of G partial sums, G window
+  // counters, then the staging buffer of one stone payload (G * MPL * 64 floats).
   extern __shared__ double lds_dyn[];
   double (*red)[G] = reinterpret_cast<double (*)[G]>(lds_dyn);
-  float* stage = reinterpret_cast<float*>(lds_dyn + 2 * G);
+  // The window whose stone comes next is looked at only when a stone is written: it lives in LDS (one slot
+  // per wave, read and written by that wave alone) instead of a scalar register that the sweeps would carry.
+  volatile int* wslot = reinterpret_cast<volatile int*>(lds_dyn + 2 * G) + 2 * (threadIdx.x >> 6);
+  auto next_window = [&]() __attribute__((always_inline)) { return __builtin_amdgcn_readfirstlane(*wslot); };
+  float* stage = reinterpret_cast<float*>(lds_dyn + 3 * G);
   claim_registers<MPL>();
   int slot = 0;
   // The two passes of a target are independent until their stones meet in the record, so they run as
@@ -608,23 +677,16 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
   const bool first_thread = threadIdx.x == 0;
   const uint64_t* rows_w = ka.rows + wbase;  // the words of this wave start here in every row
 
-  // Lanes without a state: the target's own (selfm = its bit, or 0 if its word belongs to another wave)
-  // and the padding lanes from the first incomplete word of this wave on.
-  struct Stateless {
-    uint64_t selfm, phm;
-    uint32_t selfidx, phidx;
-  };
+  // Lanes without a state: the target's own (its bit, or 0 if its word belongs to another wave) and the
+  // padding lanes from the first incomplete word of this wave on; into their fixed registers.
   auto stateless = [&]() __attribute__((always_inline)) {
     const int N = ka.p.N;
     const int full_words = N >> 6, rem = N & 63;
     const bool self_here = kw >= wbase && kw < wbase + MPL;
     const int w_ph = full_words > wbase ? full_words : wbase;
-    Stateless z;
-    z.selfm = sgpr64(self_here ? (1ull << kb) : 0ull);
-    z.selfidx = sgpr32(self_here ? 2u * (uint32_t)(kw - wbase) : 0u);
-    z.phm = sgpr64((w_ph == full_words && rem) ? ~((1ull << rem) - 1ull) : ~0ull);
-    z.phidx = sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL);
-    return z;
+    set_stateless(sgpr64(self_here ? (1ull << kb) : 0ull), sgpr32(self_here ? 2u * (uint32_t)(kw - wbase) : 0u),
+                  sgpr64((w_ph == full_words && rem) ? ~((1ull << rem) - 1ull) : ~0ull),
+                  sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL));
   };
 
   // bit of the target itself at the two forced sites; it is '1' at every other site of its list
@@ -661,12 +723,15 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     });
     double S = block_sum_regs<G>(red, slot, acc);
     double ls = 0.0;
-    int wcur = 0;
-    int stone_j = 0;  // list index at which the next alpha stone is due (window 0 starts at site 0)
-    auto emit = [&](int j, int s) __attribute__((always_inline)) {
-      while (stone_j == j) {
+    *wslot = 0;
+    // The loop counts the sites still to come (left = nd - 1 - j), so that nd itself is not needed in a scalar
+    // register at every site; the next alpha stone is due when `left` reaches stone_left (window 0 starts at site 0).
+    int stone_left = nd - 1;
+    auto emit = [&](int left, int s) __attribute__((always_inline)) {
+      while (stone_left == left) {
         KArgsPtr q = rare_args();
         const int N = q->p.N, W = q->p.W;
+        int wcur = next_window();
         uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
         if (first_thread) {
           put_u32(rec, (uint32_t)q->wb[wcur]);
@@ -675,35 +740,40 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         }
         store_states(reinterpret_cast<float*>(rec + 32), N);
         wcur++;
-        stone_j = wcur < W ? __builtin_amdgcn_readfirstlane(q->bbj_all[(long long)t * W + wcur]) : -1;
+        *wslot = wcur;
+        stone_left = wcur < W ? __builtin_amdgcn_readfirstlane(q->nd_all[t] - 1 - q->bbj_all[(long long)t * W + wcur]) : -1;
       }
     };
-    emit(0, 0);
-    const Stateless z = stateless();
+    emit(nd - 1, 0);
+    stateless();
+    set_rows_base(rows_w);
+    set_edge_mask(sk_last);
+    const uint32_t stride_bytes = 8u * (uint32_t)stride;
     double rho = ka.p.c.rho_theta;
     asm volatile("" : "+v"(rho));  // stays in a vector register: re-reading it from the argument segment would add a wait to every site
     set_thresholds(ka.p.c.lo, ka.p.c.hi);
     int s_cur = __builtin_amdgcn_readfirstlane(dk[1]);  // nd >= 2: sites 0 and L-1 are always listed
     int s_next = __builtin_amdgcn_readfirstlane(dk[2 < nd ? 2 : nd - 1]);
-    double coef_j = rec[0].coef, nx_j = rec[0].nx;  // terms of the gap before site j
+    double coef_j = sgpr_f64(rec[0].coef), nx_j = sgpr_f64(rec[0].nx);  // terms of the gap before site j
     set_site_pointer(rec + 1);
-    const uint64_t* rp = rows_w + (size_t)s_cur * stride;
+    const uint64_t* rp = row_pointer(s_cur, stride_bytes);
     sload_words<kBufA, 0, RowBatches<MPL>::size(0)>(rp);
-    for (int j = 1; j < nd; j++) {
-      if ((j & 31) == 0) rotate_priority(rank, j, 0);
+    for (int left = nd - 2; left >= 0; left--) {
+      if ((left & 31) == 0) rotate_priority(rank, left, 0);
       const double rx = S * coef_j;
-      write_stateless<MPL>(S, coef_j, z.selfm, z.selfidx, z.phm, z.phidx);
+      write_stateless<MPL, true>(S, coef_j);
       // scalars of site j+1 travel during this sweep: its successor in the list and the terms of the gap before it
       prefetch_site<true>();
-      const uint64_t skm = edge_select(j, nd - 1, sk_last);
+      const uint64_t skm = edge_mask(left, 0);
       ls += nx_j;
       double c0, c1;
-      const uint64_t* rp_next = rows_w + (size_t)s_next * stride;
+      const uint64_t* rp_next = row_pointer(s_next, stride_bytes);
       sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
       S = block_sum_regs<G>(red, slot, c0, c1);
+      const uint32_t S_high = sum_high_word<G>(S);
       int s_next2;
       fetched_site<true>(s_next2, coef_j, nx_j);  // arrived: every batch but the first has waited since the fetch
-      if (out_of_range(S)) {
+      if (!surely_in_range(S_high) && out_of_range(S)) {
         const double inv = 1.0 / S;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
           const double f = inv;
@@ -712,7 +782,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         ls += log(S);
         S = 1.0;
       }
-      emit(j, s_cur);
+      emit(left, s_cur);
       s_cur = s_next;
       s_next = s_next2;
       rp = rp_next;
@@ -742,44 +812,50 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       acc += g;
     });
     double B = block_sum_regs<G>(red, slot, acc);
-    int wcur = ka.p.W - 1;
+    *wslot = ka.p.W - 1;
     int stone_j = nd - 1;  // the last window ends at the last SNP
     // stones taken at the last SNP hold beta = 1 for every state, the target included (:427-432,:447-462)
     while (stone_j == nd - 1) {
       KArgsPtr q = rare_args();
       const int N = q->p.N;
+      int wcur = next_window();
       uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
       if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, q->p.L - 1, (float)ls);
       float* dst = reinterpret_cast<float*>(rec + 56 + (size_t)4 * N);
       for (int n = threadIdx.x; n < N; n += 64 * G) dst[n] = 1.0f;
       wcur--;
+      *wslot = wcur;
       stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
     }
-    const Stateless z = stateless();
+    stateless();
+    set_rows_base(rows_w);
+    set_edge_mask(sk_first);
+    const uint32_t stride_bytes = 8u * (uint32_t)stride;
     double rho = ka.p.c.rho_theta;
     asm volatile("" : "+v"(rho));
     set_thresholds(ka.p.c.lo, ka.p.c.hi);
     int s_cur = __builtin_amdgcn_readfirstlane(dk[nd - 2]);
     int s_prev = __builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]);
-    double coef_j = rec[nd - 1].coef, nx_j = rec[nd - 1].nx;  // terms used by the step to site j: index j + 1
+    double coef_j = sgpr_f64(rec[nd - 1].coef), nx_j = sgpr_f64(rec[nd - 1].nx);  // terms used by the step to site j: index j + 1
     set_site_pointer(rec + (nd - 2));
-    const uint64_t* rp = rows_w + (size_t)s_cur * stride;
+    const uint64_t* rp = row_pointer(s_cur, stride_bytes);
     sload_words<kBufA, 0, RowBatches<MPL>::size(0)>(rp);
     for (int j = nd - 2; j >= 0; j--) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
       const double rx = B * coef_j;
-      write_stateless<MPL>(B, coef_j, z.selfm, z.selfidx, z.phm, z.phidx);
+      write_stateless<MPL, true>(B, coef_j);
       // scalars of the step to site j-1 travel during this sweep
       prefetch_site<false>();
-      const uint64_t skm = edge_select(j, 0, sk_first);
+      const uint64_t skm = edge_mask(j, 0);
       ls += nx_j;
       double c0, c1;
-      const uint64_t* rp_next = rows_w + (size_t)s_prev * stride;
+      const uint64_t* rp_next = row_pointer(s_prev, stride_bytes);
       sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
       B = block_sum_regs<G>(red, slot, c0, c1);
+      const uint32_t B_high = sum_high_word<G>(B);
       int s_prev2;
       fetched_site<false>(s_prev2, coef_j, nx_j);
-      if (out_of_range(B)) {
+      if (!surely_in_range(B_high) && out_of_range(B)) {
         const double inv = 1.0 / B;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
           const double f = inv;
@@ -791,6 +867,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       while (stone_j == j) {
         KArgsPtr q = rare_args();
         const int N = q->p.N;
+        int wcur = next_window();
         uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
         if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, s_cur, (float)ls);
         // beta = g / emission of this site; the row words are fetched again (the registers hold the next row's by now)
@@ -821,6 +898,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
           sload_words<kBufA, 0, RB::size(0)>(rpn);  // what the next sweep expects there
         }
         wcur--;
+        *wslot = wcur;
         stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
       }
       s_cur = s_prev;
@@ -846,27 +924,29 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       acc += v ? (m ? theta_d : ntheta_d) : 0.0;
     });
     double B = block_sum_regs<G>(red, slot, acc);
-    int wcur = ka.p.W - 1;
+    *wslot = ka.p.W - 1;
     int stone_j = nd - 1;  // the last window ends at the last SNP
     // stones taken at the last SNP hold beta = 1 for every state, the target included (:427-432,:447-462)
     while (stone_j == nd - 1) {
       KArgsPtr q = rare_args();
       const int N = q->p.N;
+      int wcur = next_window();
       uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
       if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, q->p.L - 1, (float)ls);
       float* dst = reinterpret_cast<float*>(rec + 56 + (size_t)4 * N);
       for (int n = threadIdx.x; n < N; n += 64 * G) dst[n] = 1.0f;
       wcur--;
+      *wslot = wcur;
       stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
     }
-    const Stateless z = stateless();
+    stateless();
     const double rho = ka.p.c.rho_theta;
     set_thresholds(ka.p.c.lo, ka.p.c.hi);
     const double inv_nt = ka.p.c.inv_ntheta_d, inv_t = ka.p.c.inv_theta_d;
     const double w_all = ntheta_d, w_mis = theta_d - ntheta_d;
     int s_cur = __builtin_amdgcn_readfirstlane(dk[nd - 2]);
     int s_prev = __builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]);
-    double coef_j = rec[nd - 1].coef, nx_j = rec[nd - 1].nx;  // terms used by the step to site j: index j + 1
+    double coef_j = sgpr_f64(rec[nd - 1].coef), nx_j = sgpr_f64(rec[nd - 1].nx);  // terms used by the step to site j: index j + 1
     set_site_pointer(rec + (nd - 2));
     const uint64_t* rp_n = row_last;
     const uint64_t* rp_c = rows_w + (size_t)s_cur * stride;
@@ -881,7 +961,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       const double aa = rx * inv_nt;
       const double bb = rx * inv_t - aa;
       const double c1 = bb * rho;
-      write_stateless<MPL>(rx, inv_nt, z.selfm, z.selfidx, z.phm, z.phidx);
+      write_stateless<MPL, false>(rx, inv_nt);
       // scalars of the step to site j-1 travel during this sweep
       prefetch_site<false>();
       const uint64_t skn = edge_select(j, nd - 2, sk_last);
@@ -932,10 +1012,12 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       while (stone_j == j) {
         KArgsPtr q = rare_args();
         const int N = q->p.N;
+        int wcur = next_window();
         uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
         if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, s_cur, (float)ls);
         store_states(reinterpret_cast<float*>(rec + 56 + (size_t)4 * N), N);
         wcur--;
+        *wslot = wcur;
         stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
       }
       s_cur = s_prev;
@@ -961,7 +1043,7 @@ template <int MPL, int G>
 inline hipError_t launch_regs_t(const PaintArgs& a, hipStream_t st)
 {
   // the stone staging buffer must fit in the 160 KiB of LDS of a CU
-  constexpr size_t lds_bytes = (size_t)G * MPL * 256 + 2 * G * 8;
+  constexpr size_t lds_bytes = (size_t)G * MPL * 256 + 3 * G * 8;
   if constexpr (lds_bytes > 160 * 1024) {
     return hipErrorInvalidValue;
   } else {

@@ -93,7 +93,7 @@ relate::PaintConsts make_consts(int N, double theta_p, double theta_d)
   c.ntheta_d = 1.0 - theta_d;
   c.inv_theta_d = 1.0 / c.theta_d;
   c.inv_ntheta_d = 1.0 / c.ntheta_d;
-  c.lo = 1e-10;
+  c.lo = relate::kRescaleLo;
   c.hi = 1.0 / c.lo;
   c.same_theta = theta_p == theta_d ? 1 : 0;
   c.reserved = 0;

@@ -89,15 +89,9 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
     const int full_words = N >> 6, rem = N & 63;
     const bool self_here = kw >= wbase && kw < wbase + MPL;
     const int w_ph = full_words > wbase ? full_words : wbase;
-    struct {
-      uint64_t selfm, phm;
-      uint32_t selfidx, phidx;
-    } z;
-    z.selfm = sgpr64(self_here ? (1ull << kb) : 0ull);
-    z.selfidx = sgpr32(self_here ? 2u * (uint32_t)(kw - wbase) : 0u);
-    z.phm = sgpr64((w_ph == full_words && rem) ? ~((1ull << rem) - 1ull) : ~0ull);
-    z.phidx = sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL);
-    return z;
+    set_stateless(sgpr64(self_here ? (1ull << kb) : 0ull), sgpr32(self_here ? 2u * (uint32_t)(kw - wbase) : 0u),
+                  sgpr64((w_ph == full_words && rem) ? ~((1ull << rem) - 1ull) : ~0ull),
+                  sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL));
   };
 
   const int s_first = __builtin_amdgcn_readfirstlane(dk[jb]);
@@ -123,7 +117,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
     });
     double S = block_sum_regs<G>(red, slot, acc);
     if (threadIdx.x == 0) ka.logscales[row0] = (float)prev;
-    const auto z = stateless();
+    stateless();
     set_thresholds(ka.p.c.lo, ka.p.c.hi);
     int s_cur = __builtin_amdgcn_readfirstlane(dk[jb + 1]);
     int s_next = __builtin_amdgcn_readfirstlane(dk[jb + 2 < nd_chunk ? jb + 2 : nd_chunk - 1]);
@@ -135,7 +129,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
     for (int j = 1; j < nds; j++) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
       const double rx = S * coef_j;
-      write_stateless<MPL>(S, coef_j, z.selfm, z.selfidx, z.phm, z.phidx);
+      write_stateless<MPL, false>(S, coef_j);
       prefetch_site<true>();
       const uint64_t skm = edge_select(j, nds - 1, sk_last);
       prev += nx_j;
@@ -207,7 +201,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
     }
     double B = block_sum_regs<G>(red, slot, acc);
     if (threadIdx.x == 0) ka.logscales[row0 + nds - 1] = ka.logscales[row0 + nds - 1] + ls_beta;  // float + float (:929)
-    const auto z = stateless();
+    stateless();
     set_thresholds(ka.p.c.lo, ka.p.c.hi);
     const double inv_nt = ka.p.c.inv_ntheta_d, inv_t = ka.p.c.inv_theta_d;
     const double w_all = ntheta_d, w_mis = theta_d - ntheta_d;
@@ -226,7 +220,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
       const double aa = rx * inv_nt;
       const double bb = rx * inv_t - aa;
       const double c1 = bb * rho;
-      write_stateless<MPL>(rx, inv_nt, z.selfm, z.selfidx, z.phm, z.phidx);
+      write_stateless<MPL, false>(rx, inv_nt);
       prefetch_site<false>();
       const uint64_t skn = edge_select(j, nds - 2, sk_last);
       const uint64_t skc = edge_select(j, 0, sk_first);

@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
 """Build-time check of the register-resident recursion kernels (relate_amd/csrc/paint_regs.hpp).
 
-The kernels keep their state in VGPRs >= 48 and their row buffers in SGPRs >= 60, addressed by number
+The kernels keep their state in VGPRs >= 48 and their row buffers and fixed scalars in SGPRs >= 52, addressed by number
 from inline asm, and rely on the compiler staying below those limits.  This script reads the device
 assembly (hipcc -S --cuda-device-only) of the instantiation files and fails if any instruction the
-COMPILER emitted (i.e. outside the asm statements) inside a paint_kernel_r / repaint_kernel_r kernel names v48+ or s60+.
+COMPILER emitted (i.e. outside the asm statements) inside a paint_kernel_r / repaint_kernel_r kernel names v48+ or s52+.
 
     python tools/check_regs.py relate_amd/csrc/paint_regs_g1.s ...
 """
 import re
 import sys
 
-V_LIMIT, S_LIMIT = 48, 60
+V_LIMIT, S_LIMIT = 48, 52
 REG = re.compile(r"\b([vs])(\d+)\b|\b([vs])\[(\d+):(\d+)\]")
 
 
