@@ -188,7 +188,9 @@ def main():
         u_actual = 2.0 * (N - 1) * sum_nd
         t_paint = kern["paint_ms"] * 1e-3
         # algorithmic work of the recursion kernel (per launch = one chunk, all N targets)
-        f_alg = 7.0 * (N - 1) * sum_nd                      # FP64 flop: 3 per forward, 4 per backward state update
+        # FP64 flop: add, multiply, accumulate per state update in either pass (painter and data share theta here,
+        # so the backward pass runs the one-row recursion; with two thetas it takes 4 per state update)
+        f_alg = 6.0 * (N - 1) * sum_nd
         b_alg = (2.0 * ((N + 7) // 8) * sum_nd              # one packed haplotype row per site and pass
                  + 32.0 * sum_nd                            # per-gap terms, both passes
                  + float(W) * N * R                         # records written

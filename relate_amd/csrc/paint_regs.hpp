@@ -53,7 +53,6 @@ constexpr int kPhIdx = kCS + 3;    // 2 * local word of the first padding lane (
 constexpr int kSelfM = kCS + 4;    // s[kSelfM:kSelfM+1] the target's own lane (0: another wave has it)
 constexpr int kPhM = kCS + 6;      // s[kPhM:kPhM+1] padding lanes of word kPhIdx/2
 constexpr int kBufA = kCS + 8, kBufB = kCS + 16, kBufC = kCS + 24, kBufD = kCS + 32;  // 4 x 8 SGPRs of row words
-constexpr int kRL = kBufD;      // readlane results of the reduction (the D buffer is idle then in every schedule)
 constexpr int kCoefN = kCS + 40, kNxN = kCS + 42;  // prefetched per-gap terms (pairs; one 4-aligned quad)
 constexpr int kDkN = kCS + 44;  // prefetched list entry
 constexpr int kCnt = kCS + 45;  // loop counter of the padding-lane writes
@@ -191,22 +190,32 @@ __device__ __forceinline__ void sload_words(const uint64_t* p)
   else
     sload4<SB, OFF>(p);
 }
-// The MPL words of a wave as an even number of batches of at most 8 words: batch b is fetched into
-// s[kBufA..] (b even) or s[kBufC..] (b odd) while batch b-1 is computed, and with an even count the
-// first batch of the next site lands in s[kBufA..] again.  Scalar loads return out of order, so the only
-// wait there is waits for all of them: the time to hide a fetch is the length of one batch, hence
-// batches as long as the registers allow.
+// The MPL words of a wave in rounds of at most 16 words, the capacity of s[kBufA .. kBufA+31].  Scalar loads
+// return out of order, so the only wait there is waits for all of them, and the time available to hide a
+// fetch is what lies between its issue and the next wait.  A round therefore runs: additions of its words
+// (no masks) -- wait -- masked multiplications (the last use of the masks) -- fetch of the next round --
+// accumulation of its words (no masks): every fetch has two thirds of a round to arrive, the fetch for the
+// next site also the reduction, and a site takes as many waits as it has rounds.
 template <int MPL>
-struct RowBatches {
-  static constexpr int NB = ((MPL + 7) / 8 + 1) / 2 * 2;
-  static constexpr int size(int b) { return MPL / NB + (b < MPL % NB ? 1 : 0); }
-  static constexpr int first(int b)
+struct RowRounds {
+  static constexpr int NR = (MPL + 15) / 16;
+  static constexpr int size(int r) { return MPL / NR + (r < MPL % NR ? 1 : 0); }
+  static constexpr int first(int r)
   {
     int o = 0;
-    for (int i = 0; i < b; i++) o += size(i);
+    for (int i = 0; i < r; i++) o += size(i);
     return o;
   }
 };
+// words [W0, W0 + NW) of the row at p -> s[kBufA ..], word W0 + i in s[kBufA + 2i : kBufA + 2i + 1]
+template <int W0, int NW>
+__device__ __forceinline__ void sload_round(const uint64_t* p)
+{
+  static_assert(NW >= 1 && NW <= 16, "one round");
+  constexpr int na = NW < 8 ? NW : 8;
+  sload_words<kBufA, 8 * W0, na>(p);
+  if constexpr (NW > 8) sload_words<kBufC, 8 * (W0 + 8), NW - 8>(p);
+}
 // The record of a list entry (SiteRec: coef, nx, dk_fwd2, dk_bwd2), fetched during a sweep for the site
 // after it.  The two list entries land in s[kDkN] (forward) and s[kCnt] (backward); the latter doubles
 // as the loop counter of write_stateless(), which has finished before the fetch is issued.
@@ -252,16 +261,6 @@ __device__ __forceinline__ bool out_of_range(double S)
       : "v"(S), "n"(kLo), "n"(kHi)
       : "vcc", "scc");
   return m != 0;
-}
-// High word of the sum that block_sum_regs just returned.  With one wave per target it is still in the
-// scalar register the reduction read it into.
-template <int G>
-__device__ __forceinline__ uint32_t sum_high_word(double S)
-{
-  uint32_t h;
-  if constexpr (G == 1) asm volatile("s_mov_b32 %0, s[%1+1]" : "=s"(h) : "n"(kRL));
-  else h = sgpr32((uint32_t)__double2hiint(S));
-  return h;
 }
 // A sum in [2^-33, 2^33) lies strictly inside the rescale thresholds (kRescaleLo = 1e-10 and its reciprocal):
 // one scalar compare on the high word settles nearly every site; the rest (NaN and negative values included)
@@ -426,28 +425,77 @@ __device__ __forceinline__ void fwd_batch(double& c0, double& c1, double rx, dou
 #undef RELATE_FWD_OPS
 }
 
+// The three kinds of instruction of the one-row recursion on up to 4 words from state word W0 on.
+template <int W0, int NW>
+__device__ __forceinline__ void row_add(double rx)
+{
+#define RELATE_OPS : : [rx] "v"(rx), [r] "n"(kA0 + 2 * W0)
+  if constexpr (NW == 4) asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2) RELATE_FWD_ADD(3) RELATE_OPS);
+  else if constexpr (NW == 3) asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2) RELATE_OPS);
+  else if constexpr (NW == 2) asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_OPS);
+  else asm volatile(RELATE_FWD_ADD(0) RELATE_OPS);
+#undef RELATE_OPS
+}
+// masks in s[SB ..]
+template <int W0, int SB, int NW>
+__device__ __forceinline__ void row_mul(double rho, uint64_t sk)
+{
+#define RELATE_OPS : : [rho] "v"(rho), [sk] "s"(sk), [r] "n"(kA0 + 2 * W0), [s] "n"(SB) : "scc"
+  if constexpr (NW == 4)
+    asm volatile(RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2) RELATE_FWD_MUL(3) "s_mov_b64 exec, -1" RELATE_OPS);
+  else if constexpr (NW == 3) asm volatile(RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2) "s_mov_b64 exec, -1" RELATE_OPS);
+  else if constexpr (NW == 2) asm volatile(RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) "s_mov_b64 exec, -1" RELATE_OPS);
+  else asm volatile(RELATE_FWD_MUL(0) "s_mov_b64 exec, -1" RELATE_OPS);
+#undef RELATE_OPS
+}
+// sums into two accumulators, which the first words of a site initialise (FIRST)
+template <int W0, int NW, bool FIRST>
+__device__ __forceinline__ void row_acc(double& c0, double& c1)
+{
+  static_assert(!FIRST || NW >= 2, "the first words initialise both accumulators");
+#define RELATE_OPS : [c0] "+v"(c0), [c1] "+v"(c1) : [r] "n"(kA0 + 2 * W0)
+  if constexpr (NW == 4 && FIRST) asm volatile(RELATE_FWD_SUM2(c0, 0, 2) RELATE_FWD_SUM2(c1, 1, 3) RELATE_OPS);
+  else if constexpr (NW == 4) asm volatile(RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_ACC(c1, 3) RELATE_OPS);
+  else if constexpr (NW == 3 && FIRST) asm volatile(RELATE_FWD_SUM2(c0, 0, 2) RELATE_FWD_SET(c1, 1) RELATE_OPS);
+  else if constexpr (NW == 3) asm volatile(RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_OPS);
+  else if constexpr (NW == 2 && FIRST) asm volatile(RELATE_FWD_SET(c0, 0) RELATE_FWD_SET(c1, 1) RELATE_OPS);
+  else if constexpr (NW == 2) asm volatile(RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_OPS);
+  else asm volatile(RELATE_FWD_ACC(c0, 0) RELATE_OPS);
+#undef RELATE_OPS
+}
+
 // One site of the one-row recursion, state' = (state + rx) * (mismatch ? rho : 1), over the MPL words of
-// the wave; c0 + c1 = sum of the new states.  The first batch of row `rp` is already on its way into
-// s[kBufA..]; the first batch of `rp_next` is requested during the last batch.
+// the wave; c0 + c1 = sum of the new states.  The first round of row `rp` is already on its way into
+// s[kBufA ..]; the first round of `rp_next` is requested after the last multiplication.
 template <int MPL>
 __device__ __forceinline__ void sweep_row(double& c0, double& c1, double rx, double rho, uint64_t sk, const uint64_t* rp,
                                           const uint64_t* rp_next)
 {
-  using RB = RowBatches<MPL>;
-  static_for<0, RB::NB>([&](auto bc) __attribute__((always_inline)) {
-    constexpr int b = decltype(bc)::value;
-    constexpr int cur = (b & 1) ? kBufC : kBufA;
-    constexpr int nxt = (b & 1) ? kBufA : kBufC;
-    constexpr int w0 = RB::first(b), nw = RB::size(b);
+  using RR = RowRounds<MPL>;
+  static_for<0, RR::NR>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    constexpr int w0 = RR::first(r), nw = RR::size(r);
+    constexpr int NC = (nw + 3) / 4;  // groups of up to 4 words
+    static_for<0, NC>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      const double rxl = rx;
+      row_add<w0 + 4 * c, (nw - 4 * c < 4 ? nw - 4 * c : 4)>(rxl);
+    });
+    swait();
+    static_for<0, NC>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      const double rhol = rho;
+      const uint64_t skl = sk;
+      row_mul<w0 + 4 * c, kBufA + 8 * c, (nw - 4 * c < 4 ? nw - 4 * c : 4)>(rhol, skl);
+    });
     const uint64_t* rpl = rp;
     const uint64_t* rpn = rp_next;
-    swait();
-    if constexpr (b + 1 < RB::NB) sload_words<nxt, 8 * RB::first(b + 1), RB::size(b + 1)>(rpl);
-    else sload_words<nxt, 0, RB::size(0)>(rpn);
-    const double rxl = rx, rhol = rho;
-    const uint64_t skl = sk;
-    fwd_batch<w0, cur, (nw > 4 ? 4 : nw), b == 0>(c0, c1, rxl, rhol, skl);
-    if constexpr (nw > 4) fwd_batch<w0 + 4, cur + 8, nw - 4, false>(c0, c1, rxl, rhol, skl);
+    if constexpr (r + 1 < RR::NR) sload_round<RR::first(r + 1), RR::size(r + 1)>(rpl);
+    else sload_round<0, RR::size(0)>(rpn);
+    static_for<0, NC>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      row_acc<w0 + 4 * c, (nw - 4 * c < 4 ? nw - 4 * c : 4), r == 0 && c == 0>(c0, c1);
+    });
   });
 }
 
@@ -522,11 +570,11 @@ __device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, doub
   RELATE_DPP_STEP("quad_perm:[2,3,0,1]")                                                       \
   RELATE_DPP_STEP("row_half_mirror")                                                           \
   RELATE_DPP_STEP("row_mirror")                                                                \
-  "s_mov_b32 s[%[rl]+2], 0xffff0000\n\t"                                                       \
-  "s_mov_b32 s[%[rl]+3], 0xffff0000\n\t"                                                       \
+  "s_nop 1\n\t"                                                                                \
   "v_mov_b32_dpp v[%[t]], v[%[x]] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                 \
   "v_mov_b32_dpp v[%[t]+1], v[%[x]+1] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"             \
-  "s_mov_b64 exec, s[%[rl]+2:%[rl]+3]\n\t"                                                     \
+  "s_mov_b32 exec_lo, 0xffff0000\n\t"                                                         \
+  "s_mov_b32 exec_hi, 0xffff0000\n\t"                                                         \
   "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"                               \
   "s_mov_b64 exec, -1\n\t"                                                                     \
   "s_nop 0\n\t"                                                                                \
@@ -536,37 +584,42 @@ __device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, doub
   "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"                               \
   "s_mov_b64 exec, -1\n\t"                                                                     \
   "s_nop 0\n\t"                                                                                \
-  "v_readlane_b32 s[%[rl]+0], v[%[x]], 63\n\t"                                                 \
-  "v_readlane_b32 s[%[rl]+1], v[%[x]+1], 63\n\t"                                               \
+  "v_readlane_b32 vcc_lo, v[%[x]], 63\n\t"                                                     \
+  "v_readlane_b32 vcc_hi, v[%[x]+1], 63\n\t"                                                   \
   "s_nop 1\n\t"                                                                                \
-  "v_mov_b64 %[out], s[%[rl]:%[rl]+1]"
+  "v_mov_b64 %[out], vcc\n\t"                                                                  \
+  "s_mov_b32 %[hi], vcc_hi"
 
-// wave sum of x
-__device__ __forceinline__ double wave_sum_regs(double x)
+// wave sum of x; `hi` = its high word as a scalar (the lane-63 read-out passes through VCC: the row-word
+// registers may be receiving the next row by then)
+__device__ __forceinline__ double wave_sum_regs(uint32_t& hi, double x)
 {
   double out;
   asm volatile("v_mov_b64 v[%[x]:%[x]+1], %[in]\n\t" RELATE_WAVE_SUM_TAIL
-               : [out] "=v"(out)
-               : [in] "v"(x), [x] "n"(kX), [t] "n"(kT), [rl] "n"(kRL));
+               : [out] "=v"(out), [hi] "=s"(hi)
+               : [in] "v"(x), [x] "n"(kX), [t] "n"(kT)
+               : "vcc");
   return out;
 }
 // wave sum of a + b
-__device__ __forceinline__ double wave_sum_regs(double a, double b)
+__device__ __forceinline__ double wave_sum_regs(uint32_t& hi, double a, double b)
 {
   double out;
   asm volatile("v_add_f64 v[%[x]:%[x]+1], %[a], %[b]\n\t" RELATE_WAVE_SUM_TAIL
-               : [out] "=v"(out)
-               : [a] "v"(a), [b] "v"(b), [x] "n"(kX), [t] "n"(kT), [rl] "n"(kRL));
+               : [out] "=v"(out), [hi] "=s"(hi)
+               : [a] "v"(a), [b] "v"(b), [x] "n"(kX), [t] "n"(kT)
+               : "vcc");
   return out;
 }
 // wave sum of wa * a + wb * b
-__device__ __forceinline__ double wave_sum_regs(double a, double wa, double b, double wb)
+__device__ __forceinline__ double wave_sum_regs(uint32_t& hi, double a, double wa, double b, double wb)
 {
   double out;
   asm volatile("v_mul_f64 v[%[x]:%[x]+1], %[b], %[wb]\n\t"
                "v_fma_f64 v[%[x]:%[x]+1], %[a], %[wa], v[%[x]:%[x]+1]\n\t" RELATE_WAVE_SUM_TAIL
-               : [out] "=v"(out)
-               : [a] "v"(a), [wa] "v"(wa), [b] "v"(b), [wb] "v"(wb), [x] "n"(kX), [t] "n"(kT), [rl] "n"(kRL));
+               : [out] "=v"(out), [hi] "=s"(hi)
+               : [a] "v"(a), [wa] "v"(wa), [b] "v"(b), [wb] "v"(wb), [x] "n"(kX), [t] "n"(kT)
+               : "vcc");
   return out;
 }
 
@@ -574,9 +627,9 @@ __device__ __forceinline__ double wave_sum_regs(double a, double wa, double b, d
 // per call is enough (a row is rewritten two calls later, after every wave has passed the barrier of
 // the call in between).
 template <int G, class... Parts>
-__device__ __forceinline__ double block_sum_regs(double (*red)[G], int& slot, Parts... parts)
+__device__ __forceinline__ double block_sum_hi(double (*red)[G], int& slot, uint32_t& hi, Parts... parts)
 {
-  double x = wave_sum_regs(parts...);
+  double x = wave_sum_regs(hi, parts...);
   if constexpr (G == 1) {
     return x;
   } else {
@@ -587,8 +640,15 @@ __device__ __forceinline__ double block_sum_regs(double (*red)[G], int& slot, Pa
 #pragma unroll
     for (int g = 1; g < G; g++) s += red[slot][g];
     slot ^= 1;
+    hi = sgpr32((uint32_t)__double2hiint(s));
     return s;
   }
+}
+template <int G, class... Parts>
+__device__ __forceinline__ double block_sum_regs(double (*red)[G], int& slot, Parts... parts)
+{
+  uint32_t hi;
+  return block_sum_hi<G>(red, slot, hi, parts...);
 }
 
 // The instruction arbiter of a SIMD serves the oldest wave first, so of the four waves that share a SIMD
@@ -757,7 +817,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     double coef_j = sgpr_f64(rec[0].coef), nx_j = sgpr_f64(rec[0].nx);  // terms of the gap before site j
     set_site_pointer(rec + 1);
     const uint64_t* rp = row_pointer(s_cur, stride_bytes);
-    sload_words<kBufA, 0, RowBatches<MPL>::size(0)>(rp);
+    sload_round<0, RowRounds<MPL>::size(0)>(rp);
     for (int left = nd - 2; left >= 0; left--) {
       if ((left & 31) == 0) rotate_priority(rank, left, 0);
       const double rx = S * coef_j;
@@ -769,8 +829,8 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       double c0, c1;
       const uint64_t* rp_next = row_pointer(s_next, stride_bytes);
       sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
-      S = block_sum_regs<G>(red, slot, c0, c1);
-      const uint32_t S_high = sum_high_word<G>(S);
+      uint32_t S_high;
+      S = block_sum_hi<G>(red, slot, S_high, c0, c1);
       int s_next2;
       fetched_site<true>(s_next2, coef_j, nx_j);  // arrived: every batch but the first has waited since the fetch
       if (!surely_in_range(S_high) && out_of_range(S)) {
@@ -839,7 +899,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     double coef_j = sgpr_f64(rec[nd - 1].coef), nx_j = sgpr_f64(rec[nd - 1].nx);  // terms used by the step to site j: index j + 1
     set_site_pointer(rec + (nd - 2));
     const uint64_t* rp = row_pointer(s_cur, stride_bytes);
-    sload_words<kBufA, 0, RowBatches<MPL>::size(0)>(rp);
+    sload_round<0, RowRounds<MPL>::size(0)>(rp);
     for (int j = nd - 2; j >= 0; j--) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
       const double rx = B * coef_j;
@@ -851,8 +911,8 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       double c0, c1;
       const uint64_t* rp_next = row_pointer(s_prev, stride_bytes);
       sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
-      B = block_sum_regs<G>(red, slot, c0, c1);
-      const uint32_t B_high = sum_high_word<G>(B);
+      uint32_t B_high;
+      B = block_sum_hi<G>(red, slot, B_high, c0, c1);
       int s_prev2;
       fetched_site<false>(s_prev2, coef_j, nx_j);
       if (!surely_in_range(B_high) && out_of_range(B)) {
@@ -872,14 +932,14 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, s_cur, (float)ls);
         // beta = g / emission of this site; the row words are fetched again (the registers hold the next row's by now)
         {
-          using RB = RowBatches<MPL>;
+          using RR = RowRounds<MPL>;
           const double inv_match = q->p.c.inv_ntheta_d, inv_mis = q->p.c.inv_theta_d;
           swait();
-          static_for<0, RB::NB>([&](auto bc) __attribute__((always_inline)) {
-            constexpr int b = decltype(bc)::value;
-            constexpr int w0 = RB::first(b), nw = RB::size(b);
+          static_for<0, RR::NR>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int w0 = RR::first(r), nw = RR::size(r);
             const uint64_t* rpl = rp;
-            sload_words<kBufA, 8 * w0, nw>(rpl);
+            sload_round<w0, nw>(rpl);
             swait();
             static_for<0, nw>([&](auto ic) __attribute__((always_inline)) {
               constexpr int i = decltype(ic)::value;
@@ -895,7 +955,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
           for (int n = threadIdx.x; n < N; n += 64 * G) dst[n] = stage[n];
           __syncthreads();
           const uint64_t* rpn = rp_next;
-          sload_words<kBufA, 0, RB::size(0)>(rpn);  // what the next sweep expects there
+          sload_round<0, RR::size(0)>(rpn);  // what the next sweep expects there
         }
         wcur--;
         *wslot = wcur;
