@@ -7,10 +7,11 @@
 // Hence no spills, no copies at control-flow joins, and the sweep over the states is straight-line
 // code:
 //   forward   a' = (a + rx) * (mismatch ? rho : 1)           add, masked mul, accumulate  (3 per 64 states)
-//   backward  t = b + add_all; b' = mismatch' ? fma(t, rho, c1) : t   add, masked fma,
+//   backward  the same recursion on g = beta * emission when painter and data hold one theta; otherwise
+//             t = b + add_all; b' = mismatch' ? fma(t, rho, c1) : t   add, masked fma,
 //             sums of b' over all / over mismatching states  accumulate, masked accumulate (4 per 64 states)
-// "masked" = the bit-row word of the site (an SGPR pair fed by s_load_dwordx8, double-buffered one
-// 4-word batch ahead) written into EXEC, so the emission costs no vector instruction.
+// "masked" = the bit-row word of the site (an SGPR pair fed by s_load_dwordx16 / x8) written into EXEC,
+// so the emission costs no vector instruction.
 //
 // Lanes without a state (the target itself, lanes past N) never mismatch -- the target carries the
 // derived allele at its own sites and pack_rows sets the bits past N -- so their update is "+ rx":
