@@ -263,6 +263,19 @@ __device__ __forceinline__ bool out_of_range(double S)
       : "vcc", "scc");
   return m != 0;
 }
+// Rows come through the scalar cache from L2; a row that has left L2 costs the wave several times the usual
+// wait.  A vector load of the row (MPL words from p on: one dword per lane covers 32 words) issued two sites
+// ahead pulls it back in time.  The data lands in v[kJunk], which nothing reads; loops that use this keep
+// their rescale thresholds out of v[kLo..kHi+1] (out_of_range_exact).
+constexpr int kJunk = kLo;
+constexpr bool kTouchRows = true;
+template <int MPL>
+__device__ __forceinline__ void touch_row(const uint64_t* p, uint32_t lane_bytes)
+{
+  asm volatile("global_load_dword v[%2], %1, %0" ::"s"(p), "v"(lane_bytes), "n"(kJunk) : "memory");
+  if constexpr (MPL > 32) asm volatile("global_load_dword v[%2], %1, %0 offset:256" ::"s"(p), "v"(lane_bytes), "n"(kJunk) : "memory");
+  if constexpr (MPL > 64) asm volatile("global_load_dword v[%2], %1, %0 offset:512" ::"s"(p), "v"(lane_bytes), "n"(kJunk) : "memory");
+}
 // A sum in [2^-33, 2^33) lies strictly inside the rescale thresholds (kRescaleLo = 1e-10 and its reciprocal):
 // one scalar compare on the high word settles nearly every site; the rest (NaN and negative values included)
 // takes the exact comparison.
@@ -697,6 +710,13 @@ __device__ __forceinline__ KArgsPtr rare_args()
   return q;
 }
 
+// S < lo || S > hi with the thresholds fetched where they are needed (rare: see surely_in_range)
+__device__ __forceinline__ bool out_of_range_exact(double S)
+{
+  KArgsPtr q = rare_args();
+  return __builtin_amdgcn_ballot_w64(S < q->p.c.lo || S > q->p.c.hi) != 0;  // S is the same in every lane
+}
+
 template <int MPL, int G>
 __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const KArgs ka)
 {
@@ -768,6 +788,20 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     __syncthreads();
   };
 
+  // Diagnostics at the end of a pass.  Each pass ends with its own call and returns: code shared after the
+  // three branches would let the compiler move the set-up loads of a later branch into the loop of an earlier one.
+  auto finish = [&]() __attribute__((always_inline)) {
+    KArgsPtr q = rare_args();
+    if (q->trace && threadIdx.x == 0) {
+      uint64_t* tr = q->trace + (size_t)4 * blockIdx.x;
+      const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      tr[0] = ((uint64_t)xcc << 32) | hw;
+      tr[1] = trace_t0;
+      tr[2] = __builtin_amdgcn_s_memrealtime();
+      tr[3] = (uint64_t)pass | ((uint64_t)nd << 8);
+    }
+  };
+
   // ---------------- forward (src/fast_painting.cpp:214-408) ----------------
   if (pass == 0) {
     double acc = 0.0;
@@ -788,7 +822,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     // The loop counts the sites still to come (left = nd - 1 - j), so that nd itself is not needed in a scalar
     // register at every site; the next alpha stone is due when `left` reaches stone_left (window 0 starts at site 0).
     int stone_left = nd - 1;
-    auto emit = [&](int left, int s) __attribute__((always_inline)) {
+    auto emit = [&](int left) __attribute__((always_inline)) {
       while (stone_left == left) {
         KArgsPtr q = rare_args();
         const int N = q->p.N, W = q->p.W;
@@ -797,7 +831,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         if (first_thread) {
           put_u32(rec, (uint32_t)q->wb[wcur]);
           put_u32(rec + 4, (uint32_t)(q->wb[wcur + 1] - 1));
-          put_block_header(rec + 8, N, s, (float)ls);
+          put_block_header(rec + 8, N, q->dk_all[q->off[t] + (q->nd_all[t] - 1 - left)], (float)ls);
         }
         store_states(reinterpret_cast<float*>(rec + 32), N);
         wcur++;
@@ -805,36 +839,38 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         stone_left = wcur < W ? __builtin_amdgcn_readfirstlane(q->nd_all[t] - 1 - q->bbj_all[(long long)t * W + wcur]) : -1;
       }
     };
-    emit(nd - 1, 0);
+    emit(nd - 1);
     stateless();
     set_rows_base(rows_w);
     set_edge_mask(sk_last);
-    const uint32_t stride_bytes = 8u * (uint32_t)stride;
+    uint32_t stride_bytes = 8u * (uint32_t)stride;
+    asm volatile("" : "+s"(stride_bytes));  // not to be fetched again inside the loop: a scalar load there brings a wait with it
+    const uint32_t lane_bytes = 4u * (uint32_t)lane;
     double rho = ka.p.c.rho_theta;
     asm volatile("" : "+v"(rho));  // stays in a vector register: re-reading it from the argument segment would add a wait to every site
-    set_thresholds(ka.p.c.lo, ka.p.c.hi);
-    int s_cur = __builtin_amdgcn_readfirstlane(dk[1]);  // nd >= 2: sites 0 and L-1 are always listed
-    int s_next = __builtin_amdgcn_readfirstlane(dk[2 < nd ? 2 : nd - 1]);
     double coef_j = sgpr_f64(rec[0].coef), nx_j = sgpr_f64(rec[0].nx);  // terms of the gap before site j
     set_site_pointer(rec + 1);
-    const uint64_t* rp = row_pointer(s_cur, stride_bytes);
+    // nd >= 2: sites 0 and L-1 are always listed
+    const uint64_t* rp = row_pointer(__builtin_amdgcn_readfirstlane(dk[1]), stride_bytes);
+    const uint64_t* rp_next = row_pointer(__builtin_amdgcn_readfirstlane(dk[2 < nd ? 2 : nd - 1]), stride_bytes);
     sload_round<0, RowRounds<MPL>::size(0)>(rp);
     for (int left = nd - 2; left >= 0; left--) {
       if ((left & 31) == 0) rotate_priority(rank, left, 0);
       const double rx = S * coef_j;
       write_stateless<MPL, true>(S, coef_j);
-      // scalars of site j+1 travel during this sweep: its successor in the list and the terms of the gap before it
+      // scalars of site j+1 travel during this sweep: the list entry two sites on and the terms of the gap before it
       prefetch_site<true>();
       const uint64_t skm = edge_mask(left, 0);
       ls += nx_j;
       double c0, c1;
-      const uint64_t* rp_next = row_pointer(s_next, stride_bytes);
       sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
       uint32_t S_high;
       S = block_sum_hi<G>(red, slot, S_high, c0, c1);
       int s_next2;
-      fetched_site<true>(s_next2, coef_j, nx_j);  // arrived: every batch but the first has waited since the fetch
-      if (!surely_in_range(S_high) && out_of_range(S)) {
+      fetched_site<true>(s_next2, coef_j, nx_j);  // arrived: the sweep has waited since the fetch
+      const uint64_t* rp_next2 = row_pointer(s_next2, stride_bytes);
+      if constexpr (kTouchRows) touch_row<MPL>(rp_next2, lane_bytes);
+      if (!surely_in_range(S_high) && out_of_range_exact(S)) {
         const double inv = 1.0 / S;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
           const double f = inv;
@@ -843,12 +879,13 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         ls += log(S);
         S = 1.0;
       }
-      emit(left, s_cur);
-      s_cur = s_next;
-      s_next = s_next2;
+      emit(left);
       rp = rp_next;
+      rp_next = rp_next2;
     }
-    swait();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    finish();
+    return;
   }
 
   // ---------------- backward, one emission probability (src/fast_painting.cpp:410-599) ----------------
@@ -891,15 +928,15 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     stateless();
     set_rows_base(rows_w);
     set_edge_mask(sk_first);
-    const uint32_t stride_bytes = 8u * (uint32_t)stride;
+    uint32_t stride_bytes = 8u * (uint32_t)stride;
+    asm volatile("" : "+s"(stride_bytes));  // not to be fetched again inside the loop: a scalar load there brings a wait with it
+    const uint32_t lane_bytes = 4u * (uint32_t)lane;
     double rho = ka.p.c.rho_theta;
     asm volatile("" : "+v"(rho));
-    set_thresholds(ka.p.c.lo, ka.p.c.hi);
-    int s_cur = __builtin_amdgcn_readfirstlane(dk[nd - 2]);
-    int s_prev = __builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]);
     double coef_j = sgpr_f64(rec[nd - 1].coef), nx_j = sgpr_f64(rec[nd - 1].nx);  // terms used by the step to site j: index j + 1
     set_site_pointer(rec + (nd - 2));
-    const uint64_t* rp = row_pointer(s_cur, stride_bytes);
+    const uint64_t* rp = row_pointer(__builtin_amdgcn_readfirstlane(dk[nd - 2]), stride_bytes);
+    const uint64_t* rp_next = row_pointer(__builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]), stride_bytes);
     sload_round<0, RowRounds<MPL>::size(0)>(rp);
     for (int j = nd - 2; j >= 0; j--) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
@@ -910,13 +947,14 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       const uint64_t skm = edge_mask(j, 0);
       ls += nx_j;
       double c0, c1;
-      const uint64_t* rp_next = row_pointer(s_prev, stride_bytes);
       sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
       uint32_t B_high;
       B = block_sum_hi<G>(red, slot, B_high, c0, c1);
       int s_prev2;
       fetched_site<false>(s_prev2, coef_j, nx_j);
-      if (!surely_in_range(B_high) && out_of_range(B)) {
+      const uint64_t* rp_next2 = row_pointer(s_prev2, stride_bytes);
+      if constexpr (kTouchRows) touch_row<MPL>(rp_next2, lane_bytes);
+      if (!surely_in_range(B_high) && out_of_range_exact(B)) {
         const double inv = 1.0 / B;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
           const double f = inv;
@@ -930,7 +968,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         const int N = q->p.N;
         int wcur = next_window();
         uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
-        if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, s_cur, (float)ls);
+        if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, q->dk_all[q->off[t] + j], (float)ls);
         // beta = g / emission of this site; the row words are fetched again (the registers hold the next row's by now)
         {
           using RR = RowRounds<MPL>;
@@ -962,11 +1000,12 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         *wslot = wcur;
         stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
       }
-      s_cur = s_prev;
-      s_prev = s_prev2;
       rp = rp_next;
+      rp_next = rp_next2;
     }
-    swait();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    finish();
+    return;
   }
 
   // ---------------- backward, two emission probabilities (FastPainting(N, theta) beside Data::theta) ----------------
@@ -1087,17 +1126,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       rp_c = rp_p;
     }
   }
-  {
-    KArgsPtr q = rare_args();
-    if (q->trace && threadIdx.x == 0) {
-      uint64_t* tr = q->trace + (size_t)4 * blockIdx.x;
-      const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-      tr[0] = ((uint64_t)xcc << 32) | hw;
-      tr[1] = trace_t0;
-      tr[2] = __builtin_amdgcn_s_memrealtime();
-      tr[3] = (uint64_t)pass | ((uint64_t)nd << 8);
-    }
-  }
+  finish();
 }
 
 template <int MPL, int G>
