@@ -101,23 +101,39 @@ __global__ void __launch_bounds__(256) distance_matrix_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------ packing
-// chunk_<c>.hap rows ('0'/'1' bytes, src/data.cpp:541-550) -> bit rows.  One wave
-// per output word: 64 coalesced bytes in, one ballot, one 8-byte store.
+// chunk_<c>.hap rows ('0'/'1' bytes, src/data.cpp:541-550) -> bit rows.  One wave per 8 output words (512
+// haplotypes of one site): every lane takes 8 bytes with aligned 8-byte loads (two, shifted together, when the
+// row does not start on an 8-byte boundary), squeezes their low bits into one byte, and the 64 bytes of the
+// wave are the 8 words, stored coalesced.  row_stride is a multiple of 8 words, so segments never straddle rows.
 __global__ void __launch_bounds__(256) pack_rows_kernel(const uint8_t* __restrict__ seq, uint64_t* __restrict__ rows,
                                                         int N, int L, int row_stride)
 {
   const int lane = lane_id();
-  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int segs_per_row = row_stride >> 3;
+  const long long nseg = (long long)L * segs_per_row;
+  const long long total = (long long)L * N;  // bytes of seq
+  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-  const long long total = (long long)L * row_stride;
-  for (long long idx = wave; idx < total; idx += nwaves) {
-    const long long s = idx / row_stride;
-    const int n = (int)(idx - s * row_stride) * 64 + lane;
-    // lanes past N carry a set bit: a state that never mismatches (the recursion kernels rely on it
-    // or mask those lanes themselves; the transpose never looks at them)
-    const bool one = (n >= N) || seq[s * N + n] == (uint8_t)'1';
-    const unsigned long long m = __ballot(one);
-    if (lane == 0) rows[idx] = m;
+  for (long long seg = wave0; seg < nseg; seg += nwaves) {
+    const long long s = seg / segs_per_row;
+    const int part = (int)(seg - s * segs_per_row);
+    const int n0 = part * 512 + lane * 8;  // first haplotype of this lane
+    uint64_t x = 0;
+    if (n0 < N) {
+      const long long b = s * N + n0;  // first byte wanted
+      const uintptr_t addr = reinterpret_cast<uintptr_t>(seq) + (uintptr_t)b;
+      const unsigned sh = (unsigned)(addr & 7u) * 8u;
+      const uint64_t* q = reinterpret_cast<const uint64_t*>(addr & ~(uintptr_t)7);
+      // an aligned word is read only if its first wanted byte lies inside seq (it then shares a page with it)
+      x = q[0] >> sh;
+      if (sh != 0 && b + (8 - (long long)(sh >> 3)) < total) x |= q[1] << (64u - sh);
+    }
+    // bit i of `bits` = low bit of byte i ('1' = 0x31); haplotypes past N carry a set bit: a state that never
+    // mismatches (the recursion kernels rely on it; the transpose never looks at them)
+    unsigned bits = (unsigned)(((x & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+    const int valid = N - n0;  // haplotypes of this lane inside the row
+    if (valid < 8) bits |= valid <= 0 ? 0xFFu : (0xFFu << valid) & 0xFFu;
+    reinterpret_cast<uint8_t*>(rows)[seg * 64 + lane] = (uint8_t)bits;
   }
 }
 
@@ -518,9 +534,9 @@ size_t rows_alloc_bytes(int N, int L) { return ((size_t)L * row_stride_words(N) 
 
 hipError_t launch_pack_rows(const uint8_t* d_seq, uint64_t* d_rows, int N, int L, int row_stride, hipStream_t st)
 {
-  const long long words = (long long)L * row_stride;
-  long long blocks = (words + 3) / 4;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  const long long segs = (long long)L * (row_stride / 8);
+  long long blocks = (segs + 3) / 4;
+  if (blocks > 256 * 32) blocks = 256 * 32;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_seq, d_rows, N, L, row_stride);
   return hipGetLastError();
