@@ -229,29 +229,50 @@ __global__ void __launch_bounds__(256) site_terms_kernel(const int32_t* __restri
   const int t = blockIdx.y;
   const int n = nd[t];
   const long long o = off[t];
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const int s0 = dk[o + j];
-    const int s1 = (j + 1 < n) ? dk[o + j + 1] : s0 + 1;
-    double rsum = r[s0];
-    for (int s = s0 + 1; s < s1; s++) rsum += r[s];
-    double nxv = -rsum + log_ntheta;
-    double rp = 1.0 - exp(-rsum);
-    if (rp > 0.99) {
-      rp = 0.99;
-      nxv = log_small + log_ntheta;
-    }
-    const double cf = rp / ((1.0 - rp) * Nm1);
-    if (coef) {
-      coef[o + j] = cf;
-      nx[o + j] = nxv;
+  // the 24-byte records of a block are contiguous: they go through LDS and leave as coalesced 8-byte stores
+  __shared__ double staged[256 * 3];
+  static_assert(sizeof(SiteRec) == 24, "three 8-byte words per record");
+  for (int jb = blockIdx.x * blockDim.x; jb < n; jb += gridDim.x * blockDim.x) {
+    const int j = jb + threadIdx.x;
+    if (j < n) {
+      const int s0 = dk[o + j];
+      const int s1 = (j + 1 < n) ? dk[o + j + 1] : s0 + 1;
+      // left to right as the reference adds them; the loads of 8 terms go out together (one round trip
+      // instead of eight: the gaps of a wave's lanes differ, and the longest sets its pace)
+      double rsum = r[s0];
+      for (int s = s0 + 1; s < s1; s += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (s + u < s1) ? r[s + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (s + u < s1) rsum += v[u];
+      }
+      double nxv = -rsum + log_ntheta;
+      double rp = 1.0 - exp(-rsum);
+      if (rp > 0.99) {
+        rp = 0.99;
+        nxv = log_small + log_ntheta;
+      }
+      const double cf = rp / ((1.0 - rp) * Nm1);
+      if (coef) {
+        coef[o + j] = cf;
+        nx[o + j] = nxv;
+      }
+      if (rec) {
+        const int f2 = dk[o + (j + 2 < n ? j + 2 : n - 1)];
+        const int b2 = dk[o + (j > 1 ? j - 2 : 0)];
+        staged[3 * threadIdx.x] = cf;
+        staged[3 * threadIdx.x + 1] = nxv;
+        staged[3 * threadIdx.x + 2] = __hiloint2double(b2, f2);  // dk_fwd2 in the low word, dk_bwd2 in the high word
+      }
     }
     if (rec) {
-      SiteRec q;
-      q.coef = cf;
-      q.nx = nxv;
-      q.dk_fwd2 = dk[o + (j + 2 < n ? j + 2 : n - 1)];
-      q.dk_bwd2 = dk[o + (j > 1 ? j - 2 : 0)];
-      rec[o + j] = q;
+      __syncthreads();
+      const int cnt = 3 * (n - jb < (int)blockDim.x ? n - jb : (int)blockDim.x);
+      double* dst = reinterpret_cast<double*>(rec + o + jb);
+      for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = staged[i];
+      __syncthreads();
     }
   }
 }
