@@ -134,7 +134,10 @@ struct relate_plan {
   DevBuf nd, off, dk, coef, nx, bbj, bej, order;
   DevBuf trace, rec;
   // re-painting
-  std::vector<int32_t> h_bbj, h_bej;  // host copies of the stone indices, [K][W]
+  std::vector<int32_t> h_bbj, h_bej;  // host copies of the stone indices, [K][W] (fetched when first asked for)
+  std::vector<int32_t> h_order;       // launch order; a member so that the asynchronous upload may outlive prepare
+  bool stones_on_host = false;
+  hipStream_t prepare_stream = nullptr;
   DevBuf row_off, last_coef, last_nx, scratch;
   DevBuf dm_args;  // per-row arguments of the distance-matrix kernel
   std::vector<int32_t> h_nd;
@@ -368,7 +371,8 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   }
   p->sum_nd = total;
   // longest targets first: workgroups are handed out in launch order, so the tail of the launch is short
-  std::vector<int32_t> order(K);
+  std::vector<int32_t>& order = p->h_order;
+  order.resize(K);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p->h_nd[a] > p->h_nd[b]; });
 
@@ -394,12 +398,10 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   HIP_TRY(relate::launch_window_stones(p->dk.as<int32_t>(), p->off.as<int64_t>(), p->nd.as<int32_t>(), K, W,
                                        p->wb_dev.as<int32_t>(), p->bbj.as<int32_t>(), p->bej.as<int32_t>(), st));
   HIP_TRY(hipEventRecord(p->ev[3], st));
-  p->h_bbj.resize((size_t)K * W);
-  p->h_bej.resize((size_t)K * W);
-  HIP_TRY(hipMemcpyAsync(p->h_bbj.data(), p->bbj.p, sizeof(int32_t) * (size_t)K * W, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(p->h_bej.data(), p->bej.p, sizeof(int32_t) * (size_t)K * W, hipMemcpyDeviceToHost, st));
-  // `order` lives on the host stack: the copy above must have left it before we return
-  HIP_TRY(hipStreamSynchronize(st));
+  // No wait here: the recursion kernel can follow on the same stream at once.  The host copies of the stone
+  // indices are fetched by the first call that needs them (stone_indices_on_host).
+  p->stones_on_host = false;
+  p->prepare_stream = st;
   p->have_prepare = true;
   p->k_begin = k_begin;
   p->K = K;
@@ -460,10 +462,25 @@ int relate_plan_paint(relate_plan* p, void* d_out, void* stream)
   return RELATE_OK;
 }
 
+static int stone_indices_on_host(relate_plan* p)
+{
+  if (p->stones_on_host) return RELATE_OK;
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t n = (size_t)p->K * p->W;
+  p->h_bbj.resize(n);
+  p->h_bej.resize(n);
+  HIP_TRY(hipMemcpyAsync(p->h_bbj.data(), p->bbj.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, p->prepare_stream));
+  HIP_TRY(hipMemcpyAsync(p->h_bej.data(), p->bej.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, p->prepare_stream));
+  HIP_TRY(hipStreamSynchronize(p->prepare_stream));
+  p->stones_on_host = true;
+  return RELATE_OK;
+}
+
 int relate_plan_repaint_layout(relate_plan* p, int window, int64_t* total_rows, int* pitch, int64_t* row_offsets)
 {
   if (!p) return fail(RELATE_EINVAL, "null plan");
   if (p->K <= 0 || !p->have_prepare) return fail(RELATE_EINVAL, "no targets prepared");
+  if (int rc = stone_indices_on_host(p)) return rc;
   if (p->variant != 1) return fail(RELATE_EINVAL, "re-painting needs the register-resident kernel (variant 1)");
   if (window < 0 || window >= p->W) return fail(RELATE_EINVAL, "window out of range");
   int64_t rows = 0;
