@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--repaint", type=int, default=-1, metavar="W",
                     help="also time the re-painting (RePaintSection of all targets) of window W; adds a 'repaint' object")
+    ap.add_argument("--theta-data", type=float, default=0.0,
+                    help="Data::theta when it differs from the painter's 0.001 (experiments: the Rust caller's two thetas)")
     ap.add_argument("--N", type=int, default=0, help="override the number of haplotypes (experiments)")
     ap.add_argument("--L", type=int, default=0, help="override the number of SNPs (experiments)")
     args = ap.parse_args()
@@ -130,6 +132,7 @@ def main():
         N, L = args.N or N, args.L or L
         desc = f"custom {N} haplotypes x {L} SNPs"
     theta = 0.001
+    theta_data = args.theta_data if args.theta_data > 0 else theta
     seq, r = ra.synth_chunk(N, L, seed=2 + rank, skewed_map=(args.workload == "c5"))
     wb = ra.window_boundaries(seq, memory_gb=5.0)
     W = len(wb) - 1
@@ -150,7 +153,7 @@ def main():
         plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, stream)
         s = 0
         for k0 in range(0, N, kb):
-            s += plan.prepare(theta, theta, k0, min(N, k0 + kb), stream)
+            s += plan.prepare(theta, theta_data, k0, min(N, k0 + kb), stream)
             plan.paint(d_out.data_ptr(), stream)
             t = plan.timings()  # HIP events recorded on the launch stream around each stage
             kern["prepare_ms"] += t["prepare_ms"]
@@ -190,7 +193,7 @@ def main():
         # algorithmic work of the recursion kernel (per launch = one chunk, all N targets)
         # FP64 flop: add, multiply, accumulate per state update in either pass (painter and data share theta here,
         # so the backward pass runs the one-row recursion; with two thetas it takes 4 per state update)
-        f_alg = 6.0 * (N - 1) * sum_nd
+        f_alg = (6.0 if theta_data == theta else 7.0) * (N - 1) * sum_nd
         b_alg = (2.0 * ((N + 7) // 8) * sum_nd              # one packed haplotype row per site and pass
                  + 32.0 * sum_nd                            # per-gap terms, both passes
                  + float(W) * N * R                         # records written
@@ -211,7 +214,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "N": N, "L": L, "windows": W, "theta": theta,
+            "config": {"workload": f"{args.workload}: {desc}", "N": N, "L": L, "windows": W, "theta": theta, **({"theta_data": theta_data} if theta_data != theta else {}),
                        "sum_derived_sites": int(sum_nd), "chunks": world, "target_batches": (N + kb - 1) // kb,
                        "kernel_geometry": geo, "parallelism": f"{world} independent chunk(s), one per GPU"},
             "actual_state_updates_per_s": u_actual * world / dt * args.steps,

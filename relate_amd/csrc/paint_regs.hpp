@@ -569,6 +569,95 @@ __device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, doub
 #undef RELATE_BWD_OPS
 }
 
+// The masked instructions of the two-row backward recursion on up to 4 words from state word W0 on.
+// update: state = fma(state, rho, c1) where the lane mismatches the row handled one step earlier (masks s[SB ..], sk)
+template <int W0, int SB, int NW>
+__device__ __forceinline__ void row_fma(double rho, double c1, uint64_t sk)
+{
+#define RELATE_OPS : : [rho] "v"(rho), [c1] "v"(c1), [skn] "s"(sk), [r] "n"(kA0 + 2 * W0), [sn] "n"(SB) : "scc"
+  if constexpr (NW == 4)
+    asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3) "s_mov_b64 exec, -1" RELATE_OPS);
+  else if constexpr (NW == 3) asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) "s_mov_b64 exec, -1" RELATE_OPS);
+  else if constexpr (NW == 2) asm volatile(RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) "s_mov_b64 exec, -1" RELATE_OPS);
+  else asm volatile(RELATE_BWD_FMA(0) "s_mov_b64 exec, -1" RELATE_OPS);
+#undef RELATE_OPS
+}
+// sums over the states that mismatch the current row (masks s[SB ..], sk); the caller zeroes m0, m1 per site
+template <int W0, int SB, int NW>
+__device__ __forceinline__ void row_acc_mis(double& m0, double& m1, uint64_t sk)
+{
+#define RELATE_OPS : [cm0] "+v"(m0), [cm1] "+v"(m1) : [skc] "s"(sk), [r] "n"(kA0 + 2 * W0), [sc] "n"(SB) : "scc"
+  if constexpr (NW == 4)
+    asm volatile(RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2) RELATE_BWD_MIS(cm1, 3) "s_mov_b64 exec, -1" RELATE_OPS);
+  else if constexpr (NW == 3)
+    asm volatile(RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2) "s_mov_b64 exec, -1" RELATE_OPS);
+  else if constexpr (NW == 2) asm volatile(RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) "s_mov_b64 exec, -1" RELATE_OPS);
+  else asm volatile(RELATE_BWD_MIS(cm0, 0) "s_mov_b64 exec, -1" RELATE_OPS);
+#undef RELATE_OPS
+}
+
+// The two-row recursion takes the masks of two rows per word, so a round holds 8 words of each: those of the row
+// handled one step earlier in s[kBufA ..], those of the current row in s[kBufC ..].
+template <int MPL>
+struct RowRounds2 {
+  static constexpr int NR = (MPL + 7) / 8;
+  static constexpr int size(int r) { return MPL / NR + (r < MPL % NR ? 1 : 0); }
+  static constexpr int first(int r)
+  {
+    int o = 0;
+    for (int i = 0; i < r; i++) o += size(i);
+    return o;
+  }
+};
+// One site of the two-row backward recursion (src/fast_painting.cpp:488-517): t = beta + aa for every state,
+// fma(t, rho, c1) where the state mismatches row `rp_n`, then the sums of the new states over all of them
+// (a0 + a1) and over those that mismatch row `rp_c` (m0 + m1).  Rounds as in sweep_row: additions -- wait --
+// the two masked kinds -- fetch of the next round -- plain sums.  The first round of (rp_n, rp_c) is on its
+// way already; the first round of the next site, (rp_c, rp_p), is requested in the last round.
+template <int MPL>
+__device__ __forceinline__ void sweep_two_rows(double& a0, double& a1, double& m0, double& m1, double aa, double rho, double c1,
+                                               uint64_t skn, uint64_t skc, const uint64_t* rp_n, const uint64_t* rp_c,
+                                               const uint64_t* rp_p)
+{
+  using RR = RowRounds2<MPL>;
+  static_for<0, RR::NR>([&](auto rc) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    constexpr int w0 = RR::first(r), nw = RR::size(r);
+    constexpr int NC = (nw + 3) / 4;
+    static_for<0, NC>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      const double aal = aa;
+      row_add<w0 + 4 * c, (nw - 4 * c < 4 ? nw - 4 * c : 4)>(aal);
+    });
+    swait();
+    static_for<0, NC>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      const double rhol = rho, c1l = c1;
+      const uint64_t skl = skn;
+      row_fma<w0 + 4 * c, kBufA + 8 * c, (nw - 4 * c < 4 ? nw - 4 * c : 4)>(rhol, c1l, skl);
+    });
+    static_for<0, NC>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      const uint64_t skl = skc;
+      row_acc_mis<w0 + 4 * c, kBufC + 8 * c, (nw - 4 * c < 4 ? nw - 4 * c : 4)>(m0, m1, skl);
+    });
+    const uint64_t* pn = rp_n;
+    const uint64_t* pc = rp_c;
+    const uint64_t* pq = rp_p;
+    if constexpr (r + 1 < RR::NR) {
+      sload_words<kBufA, 8 * RR::first(r + 1), RR::size(r + 1)>(pn);
+      sload_words<kBufC, 8 * RR::first(r + 1), RR::size(r + 1)>(pc);
+    } else {
+      sload_words<kBufA, 0, RR::size(0)>(pc);
+      sload_words<kBufC, 0, RR::size(0)>(pq);
+    }
+    static_for<0, NC>([&](auto cc) __attribute__((always_inline)) {
+      constexpr int c = decltype(cc)::value;
+      row_acc<w0 + 4 * c, (nw - 4 * c < 4 ? nw - 4 * c : 4), r == 0 && c == 0>(a0, a1);
+    });
+  });
+}
+
 // ---- reductions ------------------------------------------------------------------------------------
 #define RELATE_DPP_STEP(ctrl)                                                            \
   "s_nop 1\n\t"                                                                          \
@@ -622,6 +711,20 @@ __device__ __forceinline__ double wave_sum_regs(uint32_t& hi, double a, double b
   asm volatile("v_add_f64 v[%[x]:%[x]+1], %[a], %[b]\n\t" RELATE_WAVE_SUM_TAIL
                : [out] "=v"(out), [hi] "=s"(hi)
                : [a] "v"(a), [b] "v"(b), [x] "n"(kX), [t] "n"(kT)
+               : "vcc");
+  return out;
+}
+// wave sum of wa * a + wb * b with the weights in scalar registers
+struct ScalarWeight {
+  double w;
+};
+__device__ __forceinline__ double wave_sum_regs(uint32_t& hi, double a, ScalarWeight wa, double b, ScalarWeight wb)
+{
+  double out;
+  asm volatile("v_mul_f64 v[%[x]:%[x]+1], %[b], %[wb]\n\t"
+               "v_fma_f64 v[%[x]:%[x]+1], %[a], %[wa], v[%[x]:%[x]+1]\n\t" RELATE_WAVE_SUM_TAIL
+               : [out] "=v"(out), [hi] "=s"(hi)
+               : [a] "v"(a), [wa] "s"(wa.w), [b] "v"(b), [wb] "s"(wb.w), [x] "n"(kX), [t] "n"(kT)
                : "vcc");
   return out;
 }
@@ -720,9 +823,7 @@ __device__ __forceinline__ bool out_of_range_exact(double S)
 template <int MPL, int G>
 __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const KArgs ka)
 {
-  static_assert(MPL >= 1 && MPL <= kMaxMPL, "states per lane");
-  constexpr int NB = (MPL + 3) / 4;  // 4-word batches per wave and site
-  constexpr int LASTW = MPL - 4 * (NB - 1);
+  static_assert(MPL >= 4 && MPL <= kMaxMPL, "states per lane");
   // Dynamic LDS (sized by the launcher): with a static allocation the compiler derives an occupancy
   // bound from it and then ignores amdgpu_num_sgpr.  Two rows of G partial sums, G window
   // counters, then the staging buffer of one stone payload (G * MPL * 64 floats).
@@ -1040,19 +1141,25 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
     }
     stateless();
-    const double rho = ka.p.c.rho_theta;
-    set_thresholds(ka.p.c.lo, ka.p.c.hi);
-    const double inv_nt = ka.p.c.inv_ntheta_d, inv_t = ka.p.c.inv_theta_d;
-    const double w_all = ntheta_d, w_mis = theta_d - ntheta_d;
-    int s_cur = __builtin_amdgcn_readfirstlane(dk[nd - 2]);
-    int s_prev = __builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]);
+    set_rows_base(rows_w);
+    set_edge_mask(sk_first);
+    uint32_t stride_bytes = 8u * (uint32_t)stride;
+    asm volatile("" : "+s"(stride_bytes));
+    const uint32_t lane_bytes = 4u * (uint32_t)lane;
+    // constants of the update in vector registers, opaque to the compiler: fetched again from the argument
+    // segment inside the loop they would bring a wait with them
+    double rho = ka.p.c.rho_theta;
+    asm volatile("" : "+v"(rho));
+    const double inv_nt = sgpr_f64(ka.p.c.inv_ntheta_d), inv_t = sgpr_f64(ka.p.c.inv_theta_d);
+    const ScalarWeight w_all = {sgpr_f64(ntheta_d)}, w_mis = {sgpr_f64(theta_d - ntheta_d)};
     double coef_j = sgpr_f64(rec[nd - 1].coef), nx_j = sgpr_f64(rec[nd - 1].nx);  // terms used by the step to site j: index j + 1
     set_site_pointer(rec + (nd - 2));
-    const uint64_t* rp_n = row_last;
-    const uint64_t* rp_c = rows_w + (size_t)s_cur * stride;
-    sload4<kBufA, 0>(rp_n);
-    sload4<kBufC, 0>(rp_c);
-    swait();
+    const uint64_t* rp_n = row_pointer(ka.p.L - 1, stride_bytes);
+    const uint64_t* rp_c = row_pointer(__builtin_amdgcn_readfirstlane(dk[nd - 2]), stride_bytes);
+    const uint64_t* rp_p = row_pointer(__builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]), stride_bytes);
+    sload_words<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
+    sload_words<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);
+    uint64_t skn = sk_last;  // the row handled before the first step is the last SNP's; every later one is a site of the target
     for (int j = nd - 2; j >= 0; j--) {
       if ((j & 31) == 0) rotate_priority(rank, j, 1);
       // beta' = (beta + mis'*b + a) * (mis' ? rho : 1), a = rx/(1-theta), b = rx/theta - a (:488-502), as
@@ -1061,46 +1168,21 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       const double aa = rx * inv_nt;
       const double bb = rx * inv_t - aa;
       const double c1 = bb * rho;
-      write_stateless<MPL, false>(rx, inv_nt);
+      write_stateless<MPL, true>(rx, inv_nt);
       // scalars of the step to site j-1 travel during this sweep
       prefetch_site<false>();
-      const uint64_t skn = edge_select(j, nd - 2, sk_last);
-      const uint64_t skc = edge_select(j, 0, sk_first);
+      const uint64_t skc = edge_mask(j, 0);
       ls += nx_j;
-      BwdAcc c;
-      c.m0 = 0.0;
-      c.m1 = 0.0;
-      const uint64_t* rp_p = rows_w + (size_t)s_prev * stride;
-      static_for<0, NB>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int b = decltype(ic)::value;
-        constexpr int curn = (b & 1) ? kBufB : kBufA;
-        constexpr int nxtn = (b & 1) ? kBufA : kBufB;
-        constexpr int curc = (b & 1) ? kBufD : kBufC;
-        constexpr int nxtc = (b & 1) ? kBufC : kBufD;
-        const uint64_t* pn = rp_n;
-        const uint64_t* pc = rp_c;
-        const uint64_t* pq = rp_p;
-        if constexpr (b + 1 < NB) {
-          sload4<nxtn, (b + 1) * 32>(pn);
-          sload4<nxtc, (b + 1) * 32>(pc);
-        } else {
-          sload4<nxtn, 0>(pc);
-          sload4<nxtc, 0>(pq);
-        }
-        const double rhol = rho, c1l = c1, aal = aa;
-        const uint64_t sknl = skn, skcl = skc;
-        bwd_batch<4 * b, curn, curc, (b + 1 < NB ? 4 : LASTW), b == 0>(c, rhol, c1l, aal, sknl, skcl);
-        swait();
-      });
-      if constexpr (NB & 1) {
-        scopy8<kBufA, kBufB>();
-        scopy8<kBufC, kBufD>();
-      }
+      double a0, a1, m0 = 0.0, m1 = 0.0;
+      sweep_two_rows<MPL>(a0, a1, m0, m1, aa, rho, c1, skn, skc, rp_n, rp_c, rp_p);
       // B = (1-theta) * sum over matching states + theta * sum over mismatching states (:509-517)
-      B = block_sum_regs<G>(red, slot, c.a0 + c.a1, w_all, c.m0 + c.m1, w_mis);
+      uint32_t B_high;
+      B = block_sum_hi<G>(red, slot, B_high, a0 + a1, w_all, m0 + m1, w_mis);
       int s_prev2;
       fetched_site<false>(s_prev2, coef_j, nx_j);
-      if (out_of_range(B)) {
+      const uint64_t* rp_p2 = row_pointer(s_prev2, stride_bytes);
+      if constexpr (kTouchRows) touch_row<MPL>(rp_p2, lane_bytes);
+      if (!surely_in_range(B_high) && out_of_range_exact(B)) {
         const double inv = 1.0 / B;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
           const double f = inv;
@@ -1114,17 +1196,18 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         const int N = q->p.N;
         int wcur = next_window();
         uint8_t* rec = q->out + ((size_t)wcur * q->p.K + t) * (56 + (size_t)8 * N);
-        if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, s_cur, (float)ls);
+        if (first_thread) put_block_header(rec + 32 + (size_t)4 * N, N, q->dk_all[q->off[t] + j], (float)ls);
         store_states(reinterpret_cast<float*>(rec + 56 + (size_t)4 * N), N);
         wcur--;
         *wslot = wcur;
         stone_j = wcur >= 0 ? __builtin_amdgcn_readfirstlane(q->bej_all[(long long)t * q->p.W + wcur]) : -1;
       }
-      s_cur = s_prev;
-      s_prev = s_prev2;
       rp_n = rp_c;
       rp_c = rp_p;
+      rp_p = rp_p2;
+      skn = ~0ull;
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }
   finish();
 }
