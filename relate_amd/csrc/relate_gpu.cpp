@@ -144,6 +144,7 @@ struct relate_plan {
   std::vector<int64_t> h_off;
   int64_t sum_nd = 0;
   relate::PaintGeometry geo{0, 0};
+  relate::PaintGeometry geo_repaint{0, 0};  // re-painting is bound by memory latency: it takes more waves per target when there are few targets
   // timing
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_pack = false, have_prepare = false, have_paint = false;
@@ -352,6 +353,15 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   const int K = k_end - k_begin, W = p->W;
   p->geo = relate::choose_geometry(p->N, p->prefer_waves, p->variant);
   if (p->geo.MPL <= 0) return fail(RELATE_ERANGE, "N is too large for the selected kernel variant");
+  p->geo_repaint = p->geo;
+  if (p->variant == 1 && p->prefer_waves == 0) {
+    // one window of K targets should fill the 4096 wave slots of the chip (4 per SIMD)
+    while (p->geo_repaint.G < 8 && (long long)K * p->geo_repaint.G < 4096) {
+      const relate::PaintGeometry g2 = relate::choose_geometry(p->N, 2 * p->geo_repaint.G, 1);
+      if (g2.G != 2 * p->geo_repaint.G || g2.MPL <= 0) break;
+      p->geo_repaint = g2;
+    }
+  }
   const relate::PaintConsts c = make_consts(p->N, theta_p, theta_d);
 
   HIP_TRY(hipEventRecord(p->ev[2], st));
@@ -492,7 +502,7 @@ int relate_plan_repaint_layout(relate_plan* p, int window, int64_t* total_rows, 
   }
   if (row_offsets) row_offsets[p->K] = rows;
   if (total_rows) *total_rows = rows;
-  if (pitch) *pitch = p->geo.G * p->geo.MPL * 64;
+  if (pitch) *pitch = p->geo_repaint.G * p->geo_repaint.MPL * 64;
   return RELATE_OK;
 }
 
@@ -541,7 +551,7 @@ int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* 
   a.K = K;
   a.c = c;
   HIP_TRY(hipEventRecord(p->ev[4], st));
-  HIP_TRY(relate::launch_repaint(a, p->geo, st));
+  HIP_TRY(relate::launch_repaint(a, p->geo_repaint, st));
   HIP_TRY(hipEventRecord(p->ev[5], st));
   p->have_paint = true;
   // the row offsets were copied from a host vector that dies with this call
