@@ -37,6 +37,15 @@ struct RepaintKArgs {
   Scal p;
 };
 typedef const __attribute__((address_space(4))) RepaintKArgs* RepaintKArgsPtr;
+// Pointers that went through an empty asm (to keep the compiler from fetching them again inside a loop) have
+// lost their provenance; without it the accesses become FLAT instructions, whose waits include the scalar-load
+// counter and with it the row fetch in flight.  These casts say "global memory" again.
+typedef __attribute__((address_space(1))) double GlobalDouble;
+typedef __attribute__((address_space(1))) float GlobalFloat;
+__device__ __forceinline__ GlobalDouble* as_global(double* p) { return (GlobalDouble*)p; }
+__device__ __forceinline__ const GlobalDouble* as_global(const double* p) { return (const GlobalDouble*)p; }
+__device__ __forceinline__ GlobalFloat* as_global(float* p) { return (GlobalFloat*)p; }
+
 __device__ __forceinline__ RepaintKArgsPtr rare_repaint_args()
 {
   RepaintKArgsPtr q = (RepaintKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -56,8 +65,6 @@ template <int MPL, int G, bool BWD>
 __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(const RepaintKArgs ka)
 {
   static_assert(MPL >= 4 && MPL <= kMaxMPL, "states per lane");
-  constexpr int NB = (MPL + 3) / 4;
-  constexpr int LASTW = MPL - 4 * (NB - 1);
   extern __shared__ double lds_dyn[];
   double (*red)[G] = reinterpret_cast<double (*)[G]>(lds_dyn);
   claim_registers<MPL>();
@@ -123,9 +130,18 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
     int s_next = __builtin_amdgcn_readfirstlane(dk[jb + 2 < nd_chunk ? jb + 2 : nd_chunk - 1]);
     double coef_j = rec[jb].coef, nx_j = rec[jb].nx;
     set_site_pointer(rec + jb + 1);
-    const uint64_t* rp = rows_w + (size_t)s_cur * stride;
-    sload4<kBufA, 0>(rp);
-    swait();
+    // what every site needs from the argument segment, fetched once and opaque to the compiler: a scalar load
+    // inside the loop would bring a wait for the row fetch in flight with it
+    double* scratch_rows = ka.scratch + row0 * pitch + col;
+    float* ls_rows = ka.logscales + row0;
+    size_t pitch_l = pitch;
+    int stride_l = stride;
+    asm volatile("" : "+s"(pitch_l), "+s"(stride_l), "+s"(ls_rows));
+    asm volatile("" : "+v"(scratch_rows));
+    double rho_l = rho;
+    asm volatile("" : "+v"(rho_l));
+    const uint64_t* rp = rows_w + (size_t)s_cur * stride_l;
+    sload_round<0, RowRounds<MPL>::size(0)>(rp);
     for (int j = 1; j < nds; j++) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
       const double rx = S * coef_j;
@@ -134,21 +150,8 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
       const uint64_t skm = edge_select(j, nds - 1, sk_last);
       prev += nx_j;
       double c0, c1;
-      const uint64_t* rp_next = rows_w + (size_t)s_next * stride;
-      static_for<0, NB>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int b = decltype(ic)::value;
-        constexpr int cur = (b & 1) ? kBufB : kBufA;
-        constexpr int nxt = (b & 1) ? kBufA : kBufB;
-        const uint64_t* rpl = rp;
-        const uint64_t* rpn = rp_next;
-        if constexpr (b + 1 < NB) sload4<nxt, (b + 1) * 32>(rpl);
-        else sload4<nxt, 0>(rpn);
-        const double rxl = rx, rhol = rho;
-        const uint64_t skl = skm;
-        fwd_batch<4 * b, cur, (b + 1 < NB ? 4 : LASTW), b == 0>(c0, c1, rxl, rhol, skl);
-        swait();
-      });
-      if constexpr (NB & 1) scopy8<kBufA, kBufB>();
+      const uint64_t* rp_next = rows_w + (size_t)s_next * stride_l;
+      sweep_row<MPL>(c0, c1, rx, rho_l, skm, rp, rp_next);
       S = block_sum_regs<G>(red, slot, c0, c1);
       int s_next2;
       fetched_site<true>(s_next2, coef_j, nx_j);
@@ -165,9 +168,8 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
         S = 1.0;
       }
       {
-        RepaintKArgsPtr q = rare_repaint_args();
-        if (threadIdx.x == 0) q->logscales[row0 + j] = lsj;
-        double* ar = q->scratch + (row0 + j) * pitch + col;
+        if (threadIdx.x == 0) as_global(ls_rows)[j] = lsj;
+        GlobalDouble* __restrict__ ar = as_global(scratch_rows + (size_t)j * pitch_l);
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
           constexpr int i = decltype(ic)::value;
           ar[(size_t)i * 64] = state_get<i>();
@@ -177,6 +179,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
       s_next = s_next2;
       rp = rp_next;
     }
+    swait();
   } else {
     // ---------------- backward (:921-1107) ----------------
     const double theta_d = ka.p.c.theta_d, ntheta_d = ka.p.c.ntheta_d;
@@ -209,66 +212,65 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
     int s_prev = __builtin_amdgcn_readfirstlane(dk[je > 1 ? je - 2 : 0]);
     double coef_j = ka.last_coef[t], nx_j = ka.last_nx[t];
     set_site_pointer(rec + (je - 1));
+    const double* scratch_rows = ka.scratch + row0 * pitch + col;
+    float* top_rows = ka.topology + row0 * pitch + col;
+    float* ls_rows = ka.logscales + row0;
+    size_t pitch_l = pitch;
+    int stride_l = stride;
+    asm volatile("" : "+s"(pitch_l), "+s"(stride_l), "+s"(ls_rows));
+    asm volatile("" : "+v"(scratch_rows), "+v"(top_rows));
+    double rho_l = rho;
+    asm volatile("" : "+v"(rho_l));
+    const double inv_nt_s = sgpr_f64(inv_nt), inv_t_s = sgpr_f64(inv_t);
+    const ScalarWeight w_all_s = {sgpr_f64(w_all)}, w_mis_s = {sgpr_f64(w_mis)};
     const uint64_t* rp_n = row_last;
-    const uint64_t* rp_c = rows_w + (size_t)s_cur * stride;
-    sload4<kBufA, 0>(rp_n);
-    sload4<kBufC, 0>(rp_c);
-    swait();
+    const uint64_t* rp_c = rows_w + (size_t)s_cur * stride_l;
+    sload_words<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
+    sload_words<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);
     for (int j = nds - 2; j >= 0; j--) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
       const double rx = B * coef_j;
-      const double aa = rx * inv_nt;
-      const double bb = rx * inv_t - aa;
-      const double c1 = bb * rho;
-      write_stateless<MPL, false>(rx, inv_nt);
+      const double aa = rx * inv_nt_s;
+      const double bb = rx * inv_t_s - aa;
+      const double c1 = bb * rho_l;
+      write_stateless<MPL, true>(rx, inv_nt_s);
       prefetch_site<false>();
       const uint64_t skn = edge_select(j, nds - 2, sk_last);
       const uint64_t skc = edge_select(j, 0, sk_first);
       prev += nx_j;
-      BwdAcc c;
-      c.m0 = 0.0;
-      c.m1 = 0.0;
-      const uint64_t* rp_p = rows_w + (size_t)s_prev * stride;
-      static_for<0, NB>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int b = decltype(ic)::value;
-        constexpr int curn = (b & 1) ? kBufB : kBufA;
-        constexpr int nxtn = (b & 1) ? kBufA : kBufB;
-        constexpr int curc = (b & 1) ? kBufD : kBufC;
-        constexpr int nxtc = (b & 1) ? kBufC : kBufD;
-        const uint64_t* pn = rp_n;
-        const uint64_t* pc = rp_c;
-        const uint64_t* pq = rp_p;
-        if constexpr (b + 1 < NB) {
-          sload4<nxtn, (b + 1) * 32>(pn);
-          sload4<nxtc, (b + 1) * 32>(pc);
-        } else {
-          sload4<nxtn, 0>(pc);
-          sload4<nxtc, 0>(pq);
-        }
-        const double rhol = rho, c1l = c1, aal = aa;
-        const uint64_t sknl = skn, skcl = skc;
-        bwd_batch<4 * b, curn, curc, (b + 1 < NB ? 4 : LASTW), b == 0>(c, rhol, c1l, aal, sknl, skcl);
-        swait();
-      });
-      if constexpr (NB & 1) {
-        scopy8<kBufA, kBufB>();
-        scopy8<kBufC, kBufD>();
-      }
-      B = block_sum_regs<G>(red, slot, c.a0 + c.a1, w_all, c.m0 + c.m1, w_mis);
+      const float ls_fwd = as_global(ls_rows)[j];  // the forward launch's logscale of this row; asked for early
+      double a0, a1, m0 = 0.0, m1 = 0.0;
+      const uint64_t* rp_p = rows_w + (size_t)s_prev * stride_l;
+      sweep_two_rows<MPL>(a0, a1, m0, m1, aa, rho_l, c1, skn, skc, rp_n, rp_c, rp_p);
+      uint32_t B_high;
+      B = block_sum_hi<G>(red, slot, B_high, a0 + a1, w_all_s, m0 + m1, w_mis_s);
       int s_prev2;
       fetched_site<false>(s_prev2, coef_j, nx_j);
-      RepaintKArgsPtr q = rare_repaint_args();
       {
         // topology row j = alpha row j * beta row j, before the beta row is rescaled (:1067-1095)
-        const double* ar = q->scratch + (row0 + j) * pitch + col;
-        float* tr = q->topology + (row0 + j) * pitch + col;
-        static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
-          constexpr int i = decltype(ic)::value;
-          tr[(size_t)i * 64] = (float)(ar[(size_t)i * 64] * state_get<i>());
+        // the loads of the whole row go out before the first store: the two rows never overlap
+        const GlobalDouble* __restrict__ ar = as_global(scratch_rows + (size_t)j * pitch_l);
+        GlobalFloat* __restrict__ tr = as_global(top_rows + (size_t)j * pitch_l);
+        // in groups of 8 words: all loads of a group, then its products and stores (left alone, the compiler
+        // keeps two loads in flight and pays a memory round trip per word)
+        constexpr int CH = 8;
+        static_for<0, (MPL + CH - 1) / CH>([&](auto gc) __attribute__((always_inline)) {
+          constexpr int g = decltype(gc)::value;
+          constexpr int n = MPL - CH * g < CH ? MPL - CH * g : CH;
+          double av[n];
+          static_for<0, n>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            av[i] = ar[(size_t)(CH * g + i) * 64];
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          static_for<0, n>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            tr[(size_t)(CH * g + i) * 64] = (float)(av[i] * state_get<CH * g + i>());
+          });
+          __builtin_amdgcn_sched_barrier(0);
         });
       }
-      float lsj = 0.0f;
-      if (threadIdx.x == 0) lsj = (float)((double)q->logscales[row0 + j] + prev);  // (:994-997)
+      float lsj = (float)((double)ls_fwd + prev);  // (:994-997)
       if (out_of_range(B)) {
         const double inv = 1.0 / B;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
@@ -280,12 +282,13 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
         lsj = (float)((double)lsj + lg);
         B = 1.0;
       }
-      if (threadIdx.x == 0) q->logscales[row0 + j] = lsj;
+      if (threadIdx.x == 0) as_global(ls_rows)[j] = lsj;
       s_cur = s_prev;
       s_prev = s_prev2;
       rp_n = rp_c;
       rp_c = rp_p;
     }
+    swait();
   }
 }
 
