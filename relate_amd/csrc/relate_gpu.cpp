@@ -355,8 +355,9 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   if (p->geo.MPL <= 0) return fail(RELATE_ERANGE, "N is too large for the selected kernel variant");
   p->geo_repaint = p->geo;
   if (p->variant == 1 && p->prefer_waves == 0) {
-    // one window of K targets should fill the 4096 wave slots of the chip (4 per SIMD)
-    while (p->geo_repaint.G < 8 && (long long)K * p->geo_repaint.G < 4096) {
+    // one window of K targets should fill most of the 4096 wave slots of the chip (4 per SIMD); measured on
+    // C2 (K = 2000): 2 waves per target 4.8 ms, 1 wave 5.9 ms, 4 waves 5.3 ms
+    while (p->geo_repaint.G < 8 && (long long)K * p->geo_repaint.G < 3072) {
       const relate::PaintGeometry g2 = relate::choose_geometry(p->N, 2 * p->geo_repaint.G, 1);
       if (g2.G != 2 * p->geo_repaint.G || g2.MPL <= 0) break;
       p->geo_repaint = g2;
