@@ -53,7 +53,7 @@ constexpr int kSelfIdx = kCS + 2;  // 2 * local word of the target's own lane
 constexpr int kPhIdx = kCS + 3;    // 2 * local word of the first padding lane (2*MPL: none)
 constexpr int kSelfM = kCS + 4;    // s[kSelfM:kSelfM+1] the target's own lane (0: another wave has it)
 constexpr int kPhM = kCS + 6;      // s[kPhM:kPhM+1] padding lanes of word kPhIdx/2
-constexpr int kBufA = kCS + 8, kBufB = kCS + 16, kBufC = kCS + 24, kBufD = kCS + 32;  // 4 x 8 SGPRs of row words
+constexpr int kBufA = kCS + 8, kBufC = kCS + 24;  // s[kBufA .. kBufA+31]: row words, as two halves of 16 registers
 constexpr int kCoefN = kCS + 40, kNxN = kCS + 42;  // prefetched per-gap terms (pairs; one 4-aligned quad)
 constexpr int kDkN = kCS + 44;  // prefetched list entry
 constexpr int kCnt = kCS + 45;  // loop counter of the padding-lane writes
@@ -172,14 +172,6 @@ __device__ __forceinline__ void sload4(const uint64_t* p)
   asm volatile("s_load_dwordx8 s[%1:%1+7], %0, %2" ::"s"(p), "n"(SB), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void swait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-template <int DST, int SRC>
-__device__ __forceinline__ void scopy8()
-{
-  asm volatile(
-      "s_mov_b64 s[%0:%0+1], s[%1:%1+1]\n\ts_mov_b64 s[%0+2:%0+3], s[%1+2:%1+3]\n\t"
-      "s_mov_b64 s[%0+4:%0+5], s[%1+4:%1+5]\n\ts_mov_b64 s[%0+6:%0+7], s[%1+6:%1+7]" ::"n"(DST),
-      "n"(SRC));
-}
 // NW (1..8) row words at p + OFF bytes -> s[SB..]: five or more travel as one 16-dword load.  The load
 // may fetch up to 3 words past the ones asked for (the packed rows are allocated with that slack).
 template <int SB, int OFF, int NW>
@@ -396,49 +388,6 @@ __device__ __forceinline__ void write_stateless(double x, double y)
 #define RELATE_FWD_SET(c, i) "v_mov_b64 %[" #c "], " RELATE_A(i) "\n\t"
 #define RELATE_FWD_SUM2(c, i, k) "v_add_f64 %[" #c "], " RELATE_A(i) ", " RELATE_A(k) "\n\t"
 
-// forward sweep over NW (1..4) words: states kA0+2*W0.., row words in s[SB..]; the sums of the new
-// states go to two accumulators, which the first batch of a site initialises (FIRST)
-template <int W0, int SB, int NW, bool FIRST>
-__device__ __forceinline__ void fwd_batch(double& c0, double& c1, double rx, double rho, uint64_t sk)
-{
-  static_assert(!FIRST || NW >= 2, "the first batch initialises both accumulators");
-#define RELATE_FWD_OPS                                                                                         \
-  : [c0] "+v"(c0), [c1] "+v"(c1)                                                                               \
-  : [rx] "v"(rx), [rho] "v"(rho), [sk] "s"(sk), [r] "n"(kA0 + 2 * W0), [s] "n"(SB)                             \
-  : "scc"
-  if constexpr (NW == 4 && FIRST)
-    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2) RELATE_FWD_ADD(3)
-                 RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2) RELATE_FWD_MUL(3)
-                 "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_SUM2(c0, 0, 2) RELATE_FWD_SUM2(c1, 1, 3) RELATE_FWD_OPS);
-  else if constexpr (NW == 4)
-    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2) RELATE_FWD_ADD(3)
-                 RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2) RELATE_FWD_MUL(3)
-                 "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_ACC(c1, 3) RELATE_FWD_OPS);
-  else if constexpr (NW == 3 && FIRST)
-    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2)
-                 RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2)
-                 "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_SUM2(c0, 0, 2) RELATE_FWD_SET(c1, 1) RELATE_FWD_OPS);
-  else if constexpr (NW == 3)
-    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_ADD(2)
-                 RELATE_FWD_MUL(0) RELATE_FWD_MUL(1) RELATE_FWD_MUL(2)
-                 "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_OPS);
-  else if constexpr (NW == 2 && FIRST)
-    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_MUL(0) RELATE_FWD_MUL(1)
-                 "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_SET(c0, 0) RELATE_FWD_SET(c1, 1) RELATE_FWD_OPS);
-  else if constexpr (NW == 2)
-    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_ADD(1) RELATE_FWD_MUL(0) RELATE_FWD_MUL(1)
-                 "s_mov_b64 exec, -1\n\t"
-                 RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_OPS);
-  else
-    asm volatile(RELATE_FWD_ADD(0) RELATE_FWD_MUL(0) "s_mov_b64 exec, -1\n\t" RELATE_FWD_ACC(c0, 0) RELATE_FWD_OPS);
-#undef RELATE_FWD_OPS
-}
-
 // The three kinds of instruction of the one-row recursion on up to 4 words from state word W0 on.
 template <int W0, int NW>
 __device__ __forceinline__ void row_add(double rx)
@@ -513,61 +462,10 @@ __device__ __forceinline__ void sweep_row(double& c0, double& c1, double rx, dou
   });
 }
 
-#define RELATE_BWD_ADD(i) "v_add_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[aa]\n\t"
 #define RELATE_BWD_FMA(i) \
   "s_andn2_b64 exec, %[skn], " RELATE_W(sn, i) "\n\tv_fma_f64 " RELATE_A(i) ", " RELATE_A(i) ", %[rho], %[c1]\n\t"
-#define RELATE_BWD_ALL(c, i) "v_add_f64 %[" #c "], %[" #c "], " RELATE_A(i) "\n\t"
-#define RELATE_BWD_SUM2(c, i, k) "v_add_f64 %[" #c "], " RELATE_A(i) ", " RELATE_A(k) "\n\t"
 #define RELATE_BWD_MIS(c, i) \
   "s_andn2_b64 exec, %[skc], " RELATE_W(sc, i) "\n\tv_add_f64 %[" #c "], %[" #c "], " RELATE_A(i) "\n\t"
-
-struct BwdAcc {
-  double a0, a1;  // sums over all states (initialised by the first batch of a site)
-  double m0, m1;  // sums over the states that mismatch at the current site (zeroed by the caller)
-};
-
-// backward sweep over NW words: update with the masks of the row handled one step earlier (s[SN..],
-// skn), sums with the masks of the current row (s[SC..], skc)
-template <int W0, int SN, int SC, int NW, bool FIRST>
-__device__ __forceinline__ void bwd_batch(BwdAcc& c, double rho, double c1, double aa, uint64_t skn, uint64_t skc)
-{
-  static_assert(!FIRST || NW == 4, "the first batch of this schedule is a full one and initialises both accumulators");
-#define RELATE_BWD_OPS                                                                                         \
-  : [ca0] "+v"(c.a0), [ca1] "+v"(c.a1), [cm0] "+v"(c.m0), [cm1] "+v"(c.m1)                                     \
-  : [rho] "v"(rho), [c1] "v"(c1), [aa] "v"(aa), [skn] "s"(skn), [skc] "s"(skc), [r] "n"(kA0 + 2 * W0),        \
-    [sn] "n"(SN), [sc] "n"(SC)                                                                                 \
-  : "scc"
-  if constexpr (NW == 4 && FIRST)
-    asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2) RELATE_BWD_ADD(3)
-                 RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3)
-                 "s_mov_b64 exec, -1\n\t"
-                 RELATE_BWD_SUM2(ca0, 0, 2) RELATE_BWD_SUM2(ca1, 1, 3)
-                 RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2) RELATE_BWD_MIS(cm1, 3)
-                 "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
-  else if constexpr (NW == 4)
-    asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2) RELATE_BWD_ADD(3)
-                 RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2) RELATE_BWD_FMA(3)
-                 "s_mov_b64 exec, -1\n\t"
-                 RELATE_BWD_ALL(ca0, 0) RELATE_BWD_ALL(ca1, 1) RELATE_BWD_ALL(ca0, 2) RELATE_BWD_ALL(ca1, 3)
-                 RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2) RELATE_BWD_MIS(cm1, 3)
-                 "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
-  else if constexpr (NW == 3)
-    asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_ADD(2)
-                 RELATE_BWD_FMA(0) RELATE_BWD_FMA(1) RELATE_BWD_FMA(2)
-                 "s_mov_b64 exec, -1\n\t"
-                 RELATE_BWD_ALL(ca0, 0) RELATE_BWD_ALL(ca1, 1) RELATE_BWD_ALL(ca0, 2)
-                 RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1) RELATE_BWD_MIS(cm0, 2)
-                 "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
-  else if constexpr (NW == 2)
-    asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_ADD(1) RELATE_BWD_FMA(0) RELATE_BWD_FMA(1)
-                 "s_mov_b64 exec, -1\n\t"
-                 RELATE_BWD_ALL(ca0, 0) RELATE_BWD_ALL(ca1, 1) RELATE_BWD_MIS(cm0, 0) RELATE_BWD_MIS(cm1, 1)
-                 "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
-  else
-    asm volatile(RELATE_BWD_ADD(0) RELATE_BWD_FMA(0) "s_mov_b64 exec, -1\n\t" RELATE_BWD_ALL(ca0, 0) RELATE_BWD_MIS(cm0, 0)
-                 "s_mov_b64 exec, -1\n\t" RELATE_BWD_OPS);
-#undef RELATE_BWD_OPS
-}
 
 // The masked instructions of the two-row backward recursion on up to 4 words from state word W0 on.
 // update: state = fma(state, rho, c1) where the lane mismatches the row handled one step earlier (masks s[SB ..], sk)
