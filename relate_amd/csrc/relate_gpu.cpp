@@ -733,21 +733,74 @@ int paint_range(relate_plan* p, double theta_p, double theta_d, int k_begin, int
   }
   void* h_out = lease.p;
   int rc = RELATE_OK;
+  // The records come back window by window, and a few host threads hand each window's slab to the sink as soon
+  // as it has arrived: the sink (a memcpy into pageable memory, or pwrite) is slower than the link, and the slabs
+  // of different windows go to different places.
+  std::vector<hipEvent_t> arrived(W, nullptr);
+  for (int w = 0; w < W; w++) {
+    hipError_t e = hipEventCreateWithFlags(&arrived[w], hipEventDisableTiming);
+    if (e != hipSuccess) {
+      for (int v = 0; v < w; v++) (void)hipEventDestroy(arrived[v]);
+      d_out.release();
+      return fail(RELATE_EGPU, std::string("hipEventCreate: ") + hipGetErrorString(e));
+    }
+  }
+  const int n_threads = std::min(4, W);
   for (int k0 = k_begin; k0 < k_end && rc == RELATE_OK; k0 += kb) {
     const int k1 = std::min(k_end, k0 + kb), nk = k1 - k0;
     rc = relate_plan_prepare(p, theta_p, theta_d, k0, k1, nullptr, nullptr);
     if (rc) break;
     rc = relate_plan_paint(p, d_out.p, nullptr);
     if (rc) break;
-    hipError_t e = hipMemcpyAsync(h_out, d_out.p, R * (size_t)W * nk, hipMemcpyDeviceToHost, p->own_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(p->own_stream);
+    const size_t slab = R * (size_t)nk;
+    hipError_t e = hipSuccess;
+    for (int w = 0; w < W && e == hipSuccess; w++) {
+      e = hipMemcpyAsync(static_cast<uint8_t*>(h_out) + (size_t)w * slab, static_cast<const uint8_t*>(d_out.p) + (size_t)w * slab,
+                         slab, hipMemcpyDeviceToHost, p->own_stream);
+      if (e == hipSuccess) e = hipEventRecord(arrived[w], p->own_stream);
+    }
     if (e != hipSuccess) {
-      rc = fail(RELATE_EGPU, std::string("painting or copy-back failed: ") + hipGetErrorString(e));
+      (void)hipStreamSynchronize(p->own_stream);
+      rc = fail(RELATE_EGPU, std::string("copy-back failed: ") + hipGetErrorString(e));
       break;
     }
-    for (int w = 0; w < W && rc == RELATE_OK; w++)
-      rc = sink(w, k0, nk, static_cast<const uint8_t*>(h_out) + (size_t)w * nk * R);
+    std::vector<int> rcs(n_threads, RELATE_OK);
+    std::vector<std::string> errs(n_threads);
+    auto drain = [&](int ti) {
+      if (hipSetDevice(p->device) != hipSuccess) {
+        rcs[ti] = RELATE_EGPU;
+        errs[ti] = "hipSetDevice failed in a copy-back thread";
+        return;
+      }
+      for (int w = ti; w < W; w += n_threads) {
+        const hipError_t ew = hipEventSynchronize(arrived[w]);
+        if (ew != hipSuccess) {
+          rcs[ti] = RELATE_EGPU;
+          errs[ti] = std::string("painting or copy-back failed: ") + hipGetErrorString(ew);
+          return;
+        }
+        const int r = sink(w, k0, nk, static_cast<const uint8_t*>(h_out) + (size_t)w * slab);
+        if (r != RELATE_OK) {
+          rcs[ti] = r;
+          errs[ti] = g_err;  // the sink's message lives in this thread
+          return;
+        }
+      }
+    };
+    if (n_threads == 1) {
+      drain(0);
+    } else {
+      std::vector<std::thread> th;
+      for (int ti = 0; ti < n_threads; ti++) th.emplace_back(drain, ti);
+      for (auto& t : th) t.join();
+    }
+    // the staging block is reused by the next batch: everything must have left the stream
+    const hipError_t es = hipStreamSynchronize(p->own_stream);
+    for (int ti = 0; ti < n_threads; ti++)
+      if (rcs[ti] != RELATE_OK && rc == RELATE_OK) rc = fail(rcs[ti], errs[ti]);
+    if (es != hipSuccess && rc == RELATE_OK) rc = fail(RELATE_EGPU, std::string("painting or copy-back failed: ") + hipGetErrorString(es));
   }
+  for (int w = 0; w < W; w++) (void)hipEventDestroy(arrived[w]);
   d_out.release();
   return rc;
 }
