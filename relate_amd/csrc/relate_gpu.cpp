@@ -74,6 +74,38 @@ struct DevBuf {
   }
 };
 
+// Page-locked host buffer that grows and is reused between calls (small arrays that cross the link inside
+// prepare: pageable memory would add a staging copy and a hidden wait to each transfer).
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes)
+  {
+    if (bytes <= cap) return RELATE_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+      p = nullptr;
+      return fail(RELATE_ENOMEM, "hipHostMalloc of " + std::to_string(want) + " bytes failed");
+    }
+    cap = want;
+    return RELATE_OK;
+  }
+  void release()
+  {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T* as() const
+  {
+    return static_cast<T*>(p);
+  }
+};
+
 relate::PaintConsts make_consts(int N, double theta_p, double theta_d)
 {
   // src/fast_painting.hpp:19-45, with the host's libm as in the reference
@@ -135,13 +167,13 @@ struct relate_plan {
   DevBuf trace, rec;
   // re-painting
   std::vector<int32_t> h_bbj, h_bej;  // host copies of the stone indices, [K][W] (fetched when first asked for)
-  std::vector<int32_t> h_order;       // launch order; a member so that the asynchronous upload may outlive prepare
+  HostBuf h_order;                    // launch order (int32); a member so that the asynchronous upload may outlive prepare
   bool stones_on_host = false;
   hipStream_t prepare_stream = nullptr;
   DevBuf row_off, last_coef, last_nx, scratch;
   DevBuf dm_args;  // per-row arguments of the distance-matrix kernel
-  std::vector<int32_t> h_nd;
-  std::vector<int64_t> h_off;
+  HostBuf h_nd;   // int32 [K]
+  HostBuf h_off;  // int64 [K]
   int64_t sum_nd = 0;
   relate::PaintGeometry geo{0, 0};
   relate::PaintGeometry geo_repaint{0, 0};  // re-painting is bound by memory latency: it takes more waves per target when there are few targets
@@ -218,6 +250,7 @@ void relate_plan_destroy(relate_plan* p)
   for (DevBuf* b : {&p->seq_own, &p->r_own, &p->wb_dev, &p->nd, &p->off, &p->dk, &p->coef, &p->nx, &p->bbj, &p->bej,
                     &p->order, &p->trace, &p->rec, &p->row_off, &p->last_coef, &p->last_nx, &p->scratch, &p->dm_args})
     b->release();
+  for (HostBuf* b : {&p->h_nd, &p->h_off, &p->h_order}) b->release();
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
@@ -368,24 +401,28 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   HIP_TRY(hipEventRecord(p->ev[2], st));
   if (int rc = p->nd.reserve(sizeof(int32_t) * (size_t)K)) return rc;
   HIP_TRY(relate::launch_count_derived(p->d_cols, p->col_stride, p->L, k_begin, K, p->nd.as<int32_t>(), st));
-  p->h_nd.resize(K);
-  HIP_TRY(hipMemcpyAsync(p->h_nd.data(), p->nd.p, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
+  // the page-locked arrays below may still be feeding the uploads of an earlier prepare on another stream
+  if (p->prepare_stream && p->prepare_stream != st) HIP_TRY(hipStreamSynchronize(p->prepare_stream));
+  if (int rc = p->h_nd.reserve(sizeof(int32_t) * (size_t)K)) return rc;
+  if (int rc = p->h_off.reserve(sizeof(int64_t) * (size_t)K)) return rc;
+  if (int rc = p->h_order.reserve(sizeof(int32_t) * (size_t)K)) return rc;
+  int32_t* h_nd = p->h_nd.as<int32_t>();
+  int64_t* h_off = p->h_off.as<int64_t>();
+  int32_t* order = p->h_order.as<int32_t>();
+  HIP_TRY(hipMemcpyAsync(h_nd, p->nd.p, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  p->h_off.resize(K);
   int64_t total = 0;
   int max_nd = 0;
   for (int t = 0; t < K; t++) {
-    p->h_off[t] = total;
-    total += p->h_nd[t];
-    max_nd = std::max(max_nd, p->h_nd[t]);
-    if (p->h_nd[t] < 2 || p->h_nd[t] > p->L) return fail(RELATE_EGPU, "derived-site count out of range (kernel fault?)");
+    h_off[t] = total;
+    total += h_nd[t];
+    max_nd = std::max(max_nd, h_nd[t]);
+    if (h_nd[t] < 2 || h_nd[t] > p->L) return fail(RELATE_EGPU, "derived-site count out of range (kernel fault?)");
   }
   p->sum_nd = total;
   // longest targets first: workgroups are handed out in launch order, so the tail of the launch is short
-  std::vector<int32_t>& order = p->h_order;
-  order.resize(K);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p->h_nd[a] > p->h_nd[b]; });
+  std::iota(order, order + K, 0);
+  std::stable_sort(order, order + K, [&](int a, int b) { return h_nd[a] > h_nd[b]; });
 
   if (int rc = p->off.reserve(sizeof(int64_t) * (size_t)K)) return rc;
   if (int rc = p->order.reserve(sizeof(int32_t) * (size_t)K)) return rc;
@@ -399,8 +436,8 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   }
   if (int rc = p->bbj.reserve(sizeof(int32_t) * (size_t)K * W)) return rc;
   if (int rc = p->bej.reserve(sizeof(int32_t) * (size_t)K * W)) return rc;
-  HIP_TRY(hipMemcpyAsync(p->off.p, p->h_off.data(), sizeof(int64_t) * (size_t)K, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(p->order.p, order.data(), sizeof(int32_t) * (size_t)K, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(p->off.p, h_off, sizeof(int64_t) * (size_t)K, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(p->order.p, order, sizeof(int32_t) * (size_t)K, hipMemcpyHostToDevice, st));
   HIP_TRY(relate::launch_fill_sites(p->d_cols, p->col_stride, p->L, k_begin, K, p->off.as<int64_t>(),
                                     p->dk.as<int32_t>(), st));
   HIP_TRY(relate::launch_site_terms(p->dk.as<int32_t>(), p->off.as<int64_t>(), p->nd.as<int32_t>(), K, max_nd, p->d_r,
