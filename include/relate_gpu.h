@@ -130,7 +130,11 @@ int relate_plan_load_packed(relate_plan* p, int N, int L, const void* d_packed, 
                             int num_windows, const int32_t* window_boundaries, void* stream);
 
 /* Per-target precompute for [k_begin,k_end): derived-site lists, per-gap recombination terms and
- * window bookkeeping (src/fast_painting.cpp:33-170).  Returns the sum of nd_k in *sum_derived. */
+ * window bookkeeping (src/fast_painting.cpp:33-170).  Returns the sum of nd_k in *sum_derived.  The call waits for
+ * the counts (it sizes its buffers with them) but not for the kernels it launches after that: like
+ * relate_plan_paint it is asynchronous with respect to `stream`, and a later call on the same stream follows
+ * in order.  relate_plan_repaint_layout uses a geometry of its own (see relate_plan_geometry): its pitch may
+ * differ from 64 * waves_per_target * states_per_lane of the painting. */
 int relate_plan_prepare(relate_plan* p, double theta_painter, double theta_data, int k_begin, int k_end,
                         int64_t* sum_derived, void* stream);
 /* Forward + backward recursion of the prepared targets (src/fast_painting.cpp:214-599); writes
