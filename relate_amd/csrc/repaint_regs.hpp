@@ -36,7 +36,6 @@ struct RepaintKArgs {
   int w, pitch;
   Scal p;
 };
-typedef const __attribute__((address_space(4))) RepaintKArgs* RepaintKArgsPtr;
 // Pointers that went through an empty asm (to keep the compiler from fetching them again inside a loop) have
 // lost their provenance; without it the accesses become FLAT instructions, whose waits include the scalar-load
 // counter and with it the row fetch in flight.  These casts say "global memory" again.
@@ -45,13 +44,6 @@ typedef __attribute__((address_space(1))) float GlobalFloat;
 __device__ __forceinline__ GlobalDouble* as_global(double* p) { return (GlobalDouble*)p; }
 __device__ __forceinline__ const GlobalDouble* as_global(const double* p) { return (const GlobalDouble*)p; }
 __device__ __forceinline__ GlobalFloat* as_global(float* p) { return (GlobalFloat*)p; }
-
-__device__ __forceinline__ RepaintKArgsPtr rare_repaint_args()
-{
-  RepaintKArgsPtr q = (RepaintKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(q));
-  return q;
-}
 
 template <int I>
 __device__ __forceinline__ double state_get()
