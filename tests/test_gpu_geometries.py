@@ -1,0 +1,29 @@
+"""Kernel geometries that the other GPU tests do not reach (run with -m gpu): 36 to 80 states per lane,
+i.e. large panels painted with fewer waves per target than the automatic choice, one theta and two.
+Targets are sampled (a range of 64 and a range of 30) so that the CPU oracle stays quick."""
+import pytest
+
+import oracle_lib as ol
+import synth_np as sy
+from test_gpu_parity import compare_records, gpu_paint
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,L,W,seed,waves", [
+    (5008, 120, 2, 31, 2),   # 2 x 40 words
+    (5008, 120, 2, 31, 1),   # 1 x 80 words
+    (5008, 120, 2, 31, 8),   # falls back to 4 x 20: 8 x 12 words would run past the padded row
+    (3000, 150, 2, 32, 1),   # 1 x 48
+    (3000, 150, 2, 32, 2),   # 2 x 24
+    (4500, 100, 2, 33, 4),   # 4 x 20
+    (2300, 200, 3, 34, 1),   # 1 x 36
+])
+def test_geometry(N, L, W, seed, waves):
+    seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=seed, r_mode="skew" if seed % 2 else "flat")
+    want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb, 0, 64)
+    got = gpu_paint(seq, r, 0.001, 0.001, wb, 1, waves, 0, 64)
+    assert compare_records(got, want, N, f"N={N} waves={waves}") < 1e-4
+    want = ol.oracle().paint_stones(seq, r, 0.001, 0.01, wb, 100, 130)
+    got = gpu_paint(seq, r, 0.001, 0.01, wb, 1, waves, 100, 130)
+    assert compare_records(got, want, N, f"N={N} waves={waves}, two thetas") < 1e-4
