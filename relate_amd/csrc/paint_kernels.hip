@@ -528,9 +528,11 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
   int G = 1;
   if (prefer_waves == 2 || prefer_waves == 4 || prefer_waves == 8) G = prefer_waves;
   // The register-resident kernel is fastest with at most 32 states per lane (120 VGPRs: four waves per
-  // SIMD); measured on MI355X: N=2000 best with 1 wave per target, N=5008 with 4.
+  // SIMD), but the eighth wave of a target costs more than it brings: measured on MI355X, N=2000 is best with
+  // 1 wave per target (6.6 ms), N=5008 with 4 x 20 words (97 ms; 2 x 40: 103), N=10000 with 4 x 40 (231 ms;
+  // 8 x 20: 284).
   if (variant == 1 && prefer_waves == 0)
-    while (G < maxG && (M + G - 1) / G > 32) G *= 2;
+    while (G < maxG && (M + G - 1) / G > (G >= 4 ? 40 : 32)) G *= 2;
   if (G > maxG) G = maxG;
   while (G < maxG && (M + G - 1) / G > mpl_max) G *= 2;
   const int need = (M + G - 1) / G;

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
     (3000, 150, 2, 32, 2),   # 2 x 24
     (4500, 100, 2, 33, 4),   # 4 x 20
     (2300, 200, 3, 34, 1),   # 1 x 36
+    (10000, 60, 2, 35, 0),   # the automatic choice for a panel of 10 000: 4 x 40
 ])
 def test_geometry(N, L, W, seed, waves):
     seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=seed, r_mode="skew" if seed % 2 else "flat")
