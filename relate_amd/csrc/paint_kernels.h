@@ -62,6 +62,8 @@ struct PaintArgs {
 struct PaintGeometry { int G, MPL; };
 // variant as in launch_paint; MPL == 0 in the result means N is out of range for that variant
 PaintGeometry choose_geometry(int N, int prefer_waves /*0 = default*/, int variant);
+// The same for a launch of K targets (K decides how many rounds of waves the chip runs).
+PaintGeometry choose_geometry_for_launch(int N, int K, int prefer_waves /*0 = default*/, int variant);
 
 int row_stride_words(int N);  // words per packed row
 size_t rows_alloc_bytes(int N, int L);  // allocation size of the packed rows, slack for chunk over-reads included

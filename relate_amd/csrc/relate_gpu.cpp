@@ -384,9 +384,9 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   HIP_TRY(hipSetDevice(p->device));
   hipStream_t st = p->pick(stream);
   const int K = k_end - k_begin, W = p->W;
-  p->geo = relate::choose_geometry(p->N, p->prefer_waves, p->variant);
+  p->geo = relate::choose_geometry_for_launch(p->N, K, p->prefer_waves, p->variant);
   if (p->geo.MPL <= 0) return fail(RELATE_ERANGE, "N is too large for the selected kernel variant");
-  p->geo_repaint = p->geo;
+  p->geo_repaint = relate::choose_geometry(p->N, p->prefer_waves, p->variant);  // one window per launch: its own rule below
   if (p->variant == 1 && p->prefer_waves == 0) {
     // one window of K targets should fill most of the 4096 wave slots of the chip (4 per SIMD); measured on
     // C2 (K = 2000): 2 waves per target 4.8 ms, 1 wave 5.9 ms, 4 waves 5.3 ms

@@ -5,7 +5,7 @@ import pytest
 
 import oracle_lib as ol
 import synth_np as sy
-from test_gpu_parity import compare_records, gpu_paint
+from test_gpu_parity import _ra, compare_records, gpu_paint
 
 pytestmark = pytest.mark.gpu
 
@@ -28,3 +28,22 @@ def test_geometry(N, L, W, seed, waves):
     want = ol.oracle().paint_stones(seq, r, 0.001, 0.01, wb, 100, 130)
     got = gpu_paint(seq, r, 0.001, 0.01, wb, 1, waves, 100, 130)
     assert compare_records(got, want, N, f"N={N} waves={waves}, two thetas") < 1e-4
+
+
+def test_automatic_choice_counts_rounds():
+    """With all 3000 targets in one launch the automatic choice is one wave of 48 words per target (two
+    rounds of waves over the chip) rather than the 2 x 24 of the size rule (three rounds); with 64 targets the
+    chip is not full and more waves per target win.  Every record of the full launch against the oracle."""
+    N, L, W = 3000, 100, 2
+    seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=36, r_mode="flat")
+    ra = _ra()
+    plan = ra.Plan(0, 1, 0)
+    plan.load_host(seq, r, wb)
+    plan.prepare(0.001, 0.001, 0, N)
+    assert plan.geometry() == {"waves_per_target": 1, "states_per_lane": 48}
+    plan.prepare(0.001, 0.001, 0, 64)
+    assert plan.geometry()["waves_per_target"] >= 2
+    plan.close()
+    want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb, 0, N)
+    got = gpu_paint(seq, r, 0.001, 0.001, wb, 1, 0, 0, N)
+    assert compare_records(got, want, N, "N=3000, all targets, automatic geometry") < 1e-4
