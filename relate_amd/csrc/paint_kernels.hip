@@ -556,47 +556,97 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
 // Geometry for a launch of K targets: the rule of choose_geometry, unless a model of the launch says that
 // another wave count is clearly (7 %) faster.  All targets of a chunk take about the same time, so a launch
 // runs in rounds: 2 K G waves (a forward and a backward workgroup per target) over 1024 SIMDs x the waves per
-// SIMD that the registers allow (512 / (56 + 2 MPL) VGPRs), fewer if the launch does not fill the chip.
+// SIMD that registers and LDS allow (waves_per_cu), fewer if the launch does not fill the chip.
 // Time per site of a round = the larger of
 //   issue:   waves per SIMD x instructions per site x ns per issue slot, with 3 instructions per word + 24
 //            (+ 29, 20, 49 for the exchange between 2, 4, 8 waves) and 3.45, 2.73, 2.24, 2.09, 1.89 ns per slot
 //            at 2, 3, 4, 5, 6 or more waves per SIMD;
-//   latency: the dependent chain of one site, 300 + 10.5 ns per word for one wave, 440 + 7, 480 + 5, 570 + 5 for
+//   latency: the dependent chain of one site, 300 + 10.5 ns per word for one wave, 420 + 13, 480 + 5, 570 + 5 for
 //            2, 4, 8 waves (what a launch of a few targets takes per site).
 // The constants are fits (3.6 % rms on the issue side) to 240 launches on MI355X: N = 1000 ... 5100, K = N / 16
 // ... N, 1 to 8 waves per target.  What the rule does not see is the number of rounds and the fill: N = K = 3000
 // is 2.93 rounds of 2 x 24 words (20.8 ms) but 1.95 rounds of 1 x 48 (16.2 ms); 375 of those targets take
 // 4.7 ms as 2 x 24 and 3.6 ms as 4 x 12.  Over the measured launches the rule is 6.7 % (geometric mean) behind the best wave
 // count, the model's choice 1.0 %, and never more than 3 % behind the rule's.
+namespace {
+
+// Waves of the kernel that a CU holds: 512 VGPRs per SIMD for 56 + 2 MPL registers per lane, and 160 KiB of LDS
+// for the stone staging of every workgroup (1 x 56 words: 3 waves per SIMD by registers, 11 per CU by LDS).
+int waves_per_cu(PaintGeometry g)
+{
+  const int by_regs = 4 * std::max(1, std::min(8, 512 / ((56 + 2 * g.MPL + 7) / 8 * 8)));
+  const int by_lds = g.G * (163840 / (g.G * g.MPL * 256 + 24 * g.G));
+  return std::max(g.G, std::min(by_regs, by_lds));
+}
+
+// ns per site of one round of waves at `occ` waves per SIMD
+double round_cost(PaintGeometry g, int occ)
+{
+  static const double ns_per_slot[9] = {0.0, 4.0, 3.45, 2.73, 2.24, 2.09, 1.89, 1.89, 1.89};
+  const double exchange = g.G == 1 ? 0.0 : g.G == 2 ? 29.0 : g.G == 4 ? 20.0 : 49.0;
+  const double issue = occ * (3.0 * g.MPL + 24.0 + exchange) * ns_per_slot[occ];
+  const double latency = g.G == 1   ? 300.0 + 10.5 * g.MPL
+                         : g.G == 2 ? 420.0 + 13.0 * g.MPL
+                         : g.G == 4 ? 480.0 + 5.0 * g.MPL
+                                    : 570.0 + 5.0 * g.MPL;
+  return std::max(issue, latency);
+}
+
+// ns per site of a launch of K targets
+double launch_cost(PaintGeometry g, int K)
+{
+  const long long waves = 2LL * K * g.G;
+  const int cu = waves_per_cu(g);
+  // workgroups do not spread evenly over a chip they do not fill: 768 waves already put two on some SIMDs
+  const int occ = (int)std::max(1LL, std::min<long long>((cu + 3) / 4, (waves + 767) / 768));
+  const long long slots = std::min(256LL * cu, 1024LL * occ);
+  return (double)((waves + slots - 1) / slots) * round_cost(g, occ);
+}
+
+}  // namespace
+
 PaintGeometry choose_geometry_for_launch(int N, int K, int prefer_waves, int variant)
 {
   const PaintGeometry rule = choose_geometry(N, prefer_waves, variant);
   if (variant != 1 || prefer_waves != 0 || rule.MPL <= 0 || K <= 0) return rule;
   if (N > 5120) return rule;  // beyond the sizes the constants were fitted on
-  auto cost = [&](PaintGeometry g) {
-    const int vgpr = (56 + 2 * g.MPL + 7) / 8 * 8;
-    const long long waves = 2LL * K * g.G;
-    // workgroups do not spread evenly over a chip they do not fill: 768 waves already put two on some SIMDs
-    const int occ = (int)std::max(1LL, std::min<long long>(std::min(8, 512 / vgpr), (waves + 767) / 768));
-    static const double ns_per_slot[9] = {0.0, 4.0, 3.45, 2.73, 2.24, 2.09, 1.89, 1.89, 1.89};
-    const double exchange = g.G == 1 ? 0.0 : g.G == 2 ? 29.0 : g.G == 4 ? 20.0 : 49.0;
-    const double issue = occ * (3.0 * g.MPL + 24.0 + exchange) * ns_per_slot[occ];
-    const double latency = g.G == 1   ? 300.0 + 10.5 * g.MPL
-                           : g.G == 2 ? 440.0 + 7.0 * g.MPL
-                           : g.G == 4 ? 480.0 + 5.0 * g.MPL
-                                      : 570.0 + 5.0 * g.MPL;
-    const long long slots = 1024LL * occ;
-    const long long rounds = (waves + slots - 1) / slots;
-    return (double)rounds * std::max(issue, latency);
-  };
   PaintGeometry best = rule;
-  double best_cost = 0.93 * cost(rule);
+  double best_cost = 0.93 * launch_cost(rule, K);
   for (int G = 1; G <= 8; G *= 2) {
     const PaintGeometry g = choose_geometry(N, G, variant);  // a nonzero wave count is taken as given
     if (g.MPL <= 0 || g.G != G) continue;
-    const double c = cost(g);
+    const double c = launch_cost(g, K);
     if (c < best_cost) {
       best = g;
+      best_cost = c;
+    }
+  }
+  return best;
+}
+
+// One launch, or two.  A launch whose last round of waves is nearly empty still pays that round in full
+// (N = K = 2000: 0.98 rounds of 1 x 32 words, 6.6 ms; N = K = 2100: 1.03 rounds of 1 x 36, 13.3 ms).  The
+// targets beyond the last full round, the shortest ones of the launch order, can go into a launch of their
+// own whose geometry suits a chip that is not full (more waves per target: the latency of a site, not the
+// issue rate, bounds it).  Taken when the model above predicts 7 % over the best single launch.
+PaintLaunches plan_paint_launches(int N, int K, int prefer_waves, int variant)
+{
+  const PaintGeometry single = choose_geometry_for_launch(N, K, prefer_waves, variant);
+  PaintLaunches best{single, 0, single};
+  if (variant != 1 || prefer_waves != 0 || single.MPL <= 0 || K <= 0 || N > 5120) return best;
+  double best_cost = 0.93 * launch_cost(single, K);
+  for (int G = 1; G <= 8; G *= 2) {
+    const PaintGeometry g = choose_geometry(N, G, variant);
+    if (g.MPL <= 0 || g.G != G) continue;
+    const int cu = waves_per_cu(g), occ = (cu + 3) / 4;
+    const int per_round = 256 * cu / (2 * G) * 97 / 100;  // targets of one round, with some room (C2 fills 98 %)
+    const int rounds = K / per_round;
+    const int tail = K - rounds * per_round;
+    if (rounds < 1 || tail < 1) continue;
+    const PaintGeometry tg = choose_geometry_for_launch(N, tail, 0, variant);
+    const double c = rounds * round_cost(g, occ) + launch_cost(tg, tail);
+    if (c < best_cost) {
+      best = {g, tail, tg};
       best_cost = c;
     }
   }
