@@ -174,11 +174,6 @@ int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, i
 int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float* ms_paint);
 /* Geometry the recursion kernel was launched with. */
 int relate_plan_geometry(const relate_plan* p, int* waves_per_target, int* states_per_lane);
-/* A painting whose last round of waves would leave most of the chip idle runs as two launches: whole rounds
- * with the geometry above, then the `targets` shortest targets with a geometry of their own (targets == 0: one
- * launch).  The records do not depend on the split.  No counterpart in the reference (a diagnostic, like
- * relate_plan_geometry). */
-int relate_plan_tail_launch(const relate_plan* p, int* targets, int* waves_per_target, int* states_per_lane);
 
 /* GPU fast_log (src/fast_log.hpp:6-21) on n floats, host in / host out: used by the parity tests. */
 int relate_fast_log(const float* in, float* out, int n, int device);

@@ -54,7 +54,6 @@ struct PaintArgs {
   uint8_t* out;            // [W][K][56+8N] records
   uint64_t* trace;         // diagnostics (or null): 4 words per workgroup of the register-resident kernel
   int N, L, W, k_begin, K;
-  int first, count;        // register-resident kernel: paint entries [first, first+count) of `order` (count 0: all K)
   PaintConsts c;
 };
 
@@ -65,14 +64,6 @@ struct PaintGeometry { int G, MPL; };
 PaintGeometry choose_geometry(int N, int prefer_waves /*0 = default*/, int variant);
 // The same for a launch of K targets (K decides how many rounds of waves the chip runs).
 PaintGeometry choose_geometry_for_launch(int N, int K, int prefer_waves /*0 = default*/, int variant);
-// K targets as one launch (tail_targets == 0) or two: the first K - tail_targets entries of the launch order with
-// `main`, whole rounds of waves over the chip, and the rest, the shortest targets, with `tail`.
-struct PaintLaunches {
-  PaintGeometry main;
-  int tail_targets;
-  PaintGeometry tail;
-};
-PaintLaunches plan_paint_launches(int N, int K, int prefer_waves /*0 = default*/, int variant);
 
 int row_stride_words(int N);  // words per packed row
 size_t rows_alloc_bytes(int N, int L);  // allocation size of the packed rows, slack for chunk over-reads included

@@ -566,16 +566,19 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
 // The constants are fits (3.6 % rms on the issue side) to 240 launches on MI355X: N = 1000 ... 5100, K = N / 16
 // ... N, 1 to 8 waves per target.  What the rule does not see is the number of rounds and the fill: N = K = 3000
 // is 2.93 rounds of 2 x 24 words (20.8 ms) but 1.95 rounds of 1 x 48 (16.2 ms); 375 of those targets take
-// 4.7 ms as 2 x 24 and 3.6 ms as 4 x 12.  Over the measured launches the rule is 6.7 % (geometric mean) behind the best wave
-// count, the model's choice 1.0 %, and never more than 3 % behind the rule's.
+// 4.7 ms as 2 x 24 and 3.6 ms as 4 x 12.  Over the measured launches the rule is 6.7 % (geometric mean) behind
+// the best wave count, the model's choice 1.0 %, and never more than 3 % behind the rule's.
 namespace {
 
-// Waves of the kernel that a CU holds: 512 VGPRs per SIMD for 56 + 2 MPL registers per lane, and 160 KiB of LDS
-// for the stone staging of every workgroup (1 x 56 words: 3 waves per SIMD by registers, 11 per CU by LDS).
+// Waves of the kernel that a CU holds: 512 VGPRs per SIMD for 56 + 2 MPL registers per lane, and 160 KiB of LDS,
+// handed out in units of 1280 bytes, for the stone staging of every workgroup.  Measured: one round takes 2048
+// targets of 1 x 36 words (16 workgroups per CU, 10 240 bytes each: the LDS exactly), 1536 of 1 x 48, but 1280
+// of 1 x 56 (3 waves per SIMD by registers, 10 workgroups per CU by LDS).
 int waves_per_cu(PaintGeometry g)
 {
   const int by_regs = 4 * std::max(1, std::min(8, 512 / ((56 + 2 * g.MPL + 7) / 8 * 8)));
-  const int by_lds = g.G * (163840 / (g.G * g.MPL * 256 + 24 * g.G));
+  const int lds_wg = (g.G * g.MPL * 256 + 24 * g.G + 1279) / 1280 * 1280;
+  const int by_lds = g.G * (163840 / lds_wg);
   return std::max(g.G, std::min(by_regs, by_lds));
 }
 
@@ -618,35 +621,6 @@ PaintGeometry choose_geometry_for_launch(int N, int K, int prefer_waves, int var
     const double c = launch_cost(g, K);
     if (c < best_cost) {
       best = g;
-      best_cost = c;
-    }
-  }
-  return best;
-}
-
-// One launch, or two.  A launch whose last round of waves is nearly empty still pays that round in full
-// (N = K = 2000: 0.98 rounds of 1 x 32 words, 6.6 ms; N = K = 2100: 1.03 rounds of 1 x 36, 13.3 ms).  The
-// targets beyond the last full round, the shortest ones of the launch order, can go into a launch of their
-// own whose geometry suits a chip that is not full (more waves per target: the latency of a site, not the
-// issue rate, bounds it).  Taken when the model above predicts 7 % over the best single launch.
-PaintLaunches plan_paint_launches(int N, int K, int prefer_waves, int variant)
-{
-  const PaintGeometry single = choose_geometry_for_launch(N, K, prefer_waves, variant);
-  PaintLaunches best{single, 0, single};
-  if (variant != 1 || prefer_waves != 0 || single.MPL <= 0 || K <= 0 || N > 5120) return best;
-  double best_cost = 0.93 * launch_cost(single, K);
-  for (int G = 1; G <= 8; G *= 2) {
-    const PaintGeometry g = choose_geometry(N, G, variant);
-    if (g.MPL <= 0 || g.G != G) continue;
-    const int cu = waves_per_cu(g), occ = (cu + 3) / 4;
-    const int per_round = 256 * cu / (2 * G) * 97 / 100;  // targets of one round, with some room (C2 fills 98 %)
-    const int rounds = K / per_round;
-    const int tail = K - rounds * per_round;
-    if (rounds < 1 || tail < 1) continue;
-    const PaintGeometry tg = choose_geometry_for_launch(N, tail, 0, variant);
-    const double c = rounds * round_cost(g, occ) + launch_cost(tg, tail);
-    if (c < best_cost) {
-      best = {g, tail, tg};
       best_cost = c;
     }
   }

@@ -1131,12 +1131,10 @@ inline hipError_t launch_regs_t(const PaintArgs& a, hipStream_t st)
     ka.nd_all = a.nd;
     ka.bbj_all = a.bbj;
     ka.bej_all = a.bej;
-    const int first = a.count > 0 ? a.first : 0, count = a.count > 0 ? a.count : a.K;
-    if (first < 0 || first + count > a.K) return hipErrorInvalidValue;
-    ka.order = a.order + first;  // the kernel takes its target from order[workgroup / 2]
+    ka.order = a.order;
     ka.wb = a.wb;
     ka.out = a.out;
-    ka.trace = a.trace ? a.trace + (size_t)8 * first : nullptr;
+    ka.trace = a.trace;
     ka.p.row_stride = a.row_stride;
     ka.p.N = a.N;
     ka.p.L = a.L;
@@ -1144,7 +1142,7 @@ inline hipError_t launch_regs_t(const PaintArgs& a, hipStream_t st)
     ka.p.k_begin = a.k_begin;
     ka.p.K = a.K;
     ka.p.c = a.c;
-    hipLaunchKernelGGL((paint_kernel_r<MPL, G>), dim3(2 * (unsigned)count), dim3(64 * G), lds_bytes, st, ka);
+    hipLaunchKernelGGL((paint_kernel_r<MPL, G>), dim3(2 * (unsigned)a.K), dim3(64 * G), lds_bytes, st, ka);
     return hipGetLastError();
   }
 }

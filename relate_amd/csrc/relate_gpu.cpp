@@ -176,8 +176,6 @@ struct relate_plan {
   HostBuf h_off;  // int64 [K]
   int64_t sum_nd = 0;
   relate::PaintGeometry geo{0, 0};
-  relate::PaintGeometry geo_tail{0, 0};  // second launch of a painting, for its last tail_targets targets
-  int tail_targets = 0;
   relate::PaintGeometry geo_repaint{0, 0};  // re-painting is bound by memory latency: it takes more waves per target when there are few targets
   // timing
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -386,10 +384,7 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   HIP_TRY(hipSetDevice(p->device));
   hipStream_t st = p->pick(stream);
   const int K = k_end - k_begin, W = p->W;
-  const relate::PaintLaunches launches = relate::plan_paint_launches(p->N, K, p->prefer_waves, p->variant);
-  p->geo = launches.main;
-  p->geo_tail = launches.tail;
-  p->tail_targets = launches.tail_targets;
+  p->geo = relate::choose_geometry_for_launch(p->N, K, p->prefer_waves, p->variant);
   if (p->geo.MPL <= 0) return fail(RELATE_ERANGE, "N is too large for the selected kernel variant");
   p->geo_repaint = relate::choose_geometry(p->N, p->prefer_waves, p->variant);  // one window per launch: its own rule below
   if (p->variant == 1 && p->prefer_waves == 0) {
@@ -489,8 +484,6 @@ int relate_plan_paint(relate_plan* p, void* d_out, void* stream)
   a.W = p->W;
   a.k_begin = p->k_begin;
   a.K = p->K;
-  a.first = 0;
-  a.count = 0;
   a.c = make_consts(p->N, p->theta_p, p->theta_d);
   a.trace = nullptr;
   // Diagnostics: RELATE_TRACE=<file> makes the register-resident kernel record, per workgroup, where it
@@ -502,17 +495,7 @@ int relate_plan_paint(relate_plan* p, void* d_out, void* stream)
     a.trace = p->trace.as<uint64_t>();
   }
   HIP_TRY(hipEventRecord(p->ev[4], st));
-  if (p->tail_targets > 0 && p->tail_targets < p->K) {
-    // whole rounds of waves first, then the shortest targets in a launch shaped for a chip that is not full
-    a.first = 0;
-    a.count = p->K - p->tail_targets;
-    HIP_TRY(relate::launch_paint(a, p->geo, p->variant, st));
-    a.first = a.count;
-    a.count = p->tail_targets;
-    HIP_TRY(relate::launch_paint(a, p->geo_tail, p->variant, st));
-  } else {
-    HIP_TRY(relate::launch_paint(a, p->geo, p->variant, st));
-  }
+  HIP_TRY(relate::launch_paint(a, p->geo, p->variant, st));
   HIP_TRY(hipEventRecord(p->ev[5], st));
   p->have_paint = true;
   if (a.trace) {
@@ -678,15 +661,6 @@ int relate_plan_geometry(const relate_plan* p, int* waves, int* mpl)
   if (!p) return fail(RELATE_EINVAL, "null plan");
   if (waves) *waves = p->geo.G;
   if (mpl) *mpl = p->geo.MPL;
-  return RELATE_OK;
-}
-
-int relate_plan_tail_launch(const relate_plan* p, int* targets, int* waves, int* mpl)
-{
-  if (!p) return fail(RELATE_EINVAL, "null plan");
-  if (targets) *targets = p->tail_targets;
-  if (waves) *waves = p->tail_targets > 0 ? p->geo_tail.G : 0;
-  if (mpl) *mpl = p->tail_targets > 0 ? p->geo_tail.MPL : 0;
   return RELATE_OK;
 }
 

@@ -179,12 +179,6 @@ class Plan:
         check(lib().relate_plan_geometry(self._h, C.byref(g), C.byref(m)))
         return {"waves_per_target": g.value, "states_per_lane": m.value}
 
-    def tail_launch(self):
-        """Targets, waves per target and states per lane of the second launch of a painting (targets 0: none)."""
-        t, g, m = C.c_int(), C.c_int(), C.c_int()
-        check(lib().relate_plan_tail_launch(self._h, C.byref(t), C.byref(g), C.byref(m)))
-        return {"targets": t.value, "waves_per_target": g.value, "states_per_lane": m.value}
-
 
 def fast_log(x, device=0):
     """GPU fast_log (src/fast_log.hpp:6-21) of a float32 array."""

@@ -47,25 +47,3 @@ def test_automatic_choice_counts_rounds():
     want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb, 0, N)
     got = gpu_paint(seq, r, 0.001, 0.001, wb, 1, 0, 0, N)
     assert compare_records(got, want, N, "N=3000, all targets, automatic geometry") < 1e-4
-
-
-@pytest.mark.parametrize("N,L,K,tail", [
-    (2100, 100, 2100, (114, 2, 20)),   # 1986 targets fill the chip once as 1 x 36; the other 114 go as 2 x 20
-    (3300, 80, 3300, (570, 2, 28)),    # two rounds of 1 x 56 (11 workgroups per CU: LDS) and a tail
-    (2000, 100, 2000, (0, 0, 0)),      # fits one round: one launch
-])
-def test_split_launch(N, L, K, tail):
-    """A painting whose last round of waves would be nearly empty runs as two launches with different
-    geometries; the records are those of the oracle either way, one theta and two."""
-    seq, r, wb = sy.make_chunk(N=N, L=L, W=2, seed=37, r_mode="skew")
-    ra = _ra()
-    plan = ra.Plan(0, 1, 0)
-    plan.load_host(seq, r, wb)
-    plan.prepare(0.001, 0.001, 0, K)
-    t = plan.tail_launch()
-    plan.close()
-    assert (t["targets"], t["waves_per_target"], t["states_per_lane"]) == tail
-    for td in (0.001, 0.01):
-        want = ol.oracle().paint_stones(seq, r, 0.001, td, wb, 0, K)
-        got = gpu_paint(seq, r, 0.001, td, wb, 1, 0, 0, K)
-        assert compare_records(got, want, N, f"N={N} K={K} theta_data={td}, split launch") < 1e-4
