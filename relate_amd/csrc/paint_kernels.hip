@@ -567,7 +567,8 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
 // ... N, 1 to 8 waves per target.  What the rule does not see is the number of rounds and the fill: N = K = 3000
 // is 2.93 rounds of 2 x 24 words (20.8 ms) but 1.95 rounds of 1 x 48 (16.2 ms); 375 of those targets take
 // 4.7 ms as 2 x 24 and 3.6 ms as 4 x 12.  Over the measured launches the rule is 6.7 % (geometric mean) behind
-// the best wave count, the model's choice 1.0 %, and never more than 3 % behind the rule's.
+// the best wave count, the model's choice 0.8 %, and at most 4 % behind the rule's (N = K = 2300, one theta:
+// 15.0 ms as 1 x 36 against 14.4; with two thetas 16.8 against 18.3).
 namespace {
 
 // Waves of the kernel that a CU holds: 512 VGPRs per SIMD for 56 + 2 MPL registers per lane, and 160 KiB of LDS,
@@ -603,7 +604,12 @@ double launch_cost(PaintGeometry g, int K)
   // workgroups do not spread evenly over a chip they do not fill: 768 waves already put two on some SIMDs
   const int occ = (int)std::max(1LL, std::min<long long>((cu + 3) / 4, (waves + 767) / 768));
   const long long slots = std::min(256LL * cu, 1024LL * occ);
-  return (double)((waves + slots - 1) / slots) * round_cost(g, occ);
+  const long long rounds = (waves + slots - 1) / slots;
+  // the last round runs at the occupancy its waves reach (N = K = 2100 as 1 x 36: 8.25 ms for the full round,
+  // 4.7 ms for the 52 targets of the second)
+  const long long rest = waves - (rounds - 1) * slots;
+  const int occ_last = (int)std::max(1LL, std::min<long long>(occ, (rest + 767) / 768));
+  return (double)(rounds - 1) * round_cost(g, occ) + round_cost(g, occ_last);
 }
 
 }  // namespace
