@@ -172,7 +172,9 @@ int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, i
 /* Milliseconds of the last pack / prepare / paint, from HIP events on the stream they ran on
  * (blocks until the paint has finished); after relate_plan_repaint, ms_paint is the time of its two launches. */
 int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float* ms_paint);
-/* Geometry the recursion kernel was launched with. */
+/* Geometry the recursion kernel was launched with.  relate_plan_prepare chooses it from the panel size and the
+ * number of targets of the range (how many rounds of waves the launch makes over the chip), so two ranges of one
+ * chunk may be painted with different geometries; the records do not depend on it. */
 int relate_plan_geometry(const relate_plan* p, int* waves_per_target, int* states_per_lane);
 
 /* GPU fast_log (src/fast_log.hpp:6-21) on n floats, host in / host out: used by the parity tests. */
