@@ -513,44 +513,69 @@ hipError_t launch_plain_t(const PaintArgs& a, hipStream_t st)
 }  // namespace
 
 // ------------------------------------------------------------------ host side
-int row_stride_words(int N) { return ((N + 63) / 64 + 7) / 8 * 8; }
-int col_stride_words(int L) { return (L + 63) / 64; }
-
 // Plain-HIP kernels exist for a few small geometries only (cross-check of the register-resident ones).
 static const int kMplPlain[] = {1, 4, 16};
 static const int kMplRegs[] = {4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 48, 56, 64, 72, 80};
 
+// Words per lane of the register-resident kernel with G waves for M words per row (0: none)
+static int regs_words_per_lane(int M, int G)
+{
+  const int need = (M + G - 1) / G;
+  for (int m : kMplRegs)
+    if (m >= need) return (G == 8 && m == 80) ? 0 : m;  // 8 x 80: stone staging would exceed the LDS of a CU
+  return 0;
+}
+
+// Words per packed row: a multiple of 8 that holds the N bits and, beyond 80 words, all G x MPL words that the
+// narrowest kernel geometry reads of a row (it needs the zero padding bits of every word it reads: 88 words
+// of bits take 96, as 4 x 24, 2 x 48 or 8 x 12).
+int row_stride_words(int N)
+{
+  const int M = (N + 63) / 64;
+  int stride = (M + 7) / 8 * 8;
+  if (M > 80) {
+    int narrowest = 0;
+    for (int G = 2; G <= 8; G *= 2) {
+      const int mpl = regs_words_per_lane(M, G);
+      if (mpl > 0 && (narrowest == 0 || G * mpl < narrowest)) narrowest = G * mpl;
+    }
+    if (narrowest > stride) stride = (narrowest + 7) / 8 * 8;
+  }
+  return stride;
+}
+int col_stride_words(int L) { return (L + 63) / 64; }
+
 PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
 {
   const int M = (N + 63) / 64;
-  const int* tab = variant == 0 ? kMplPlain : kMplRegs;
-  const int ntab = variant == 0 ? 3 : 15;
   const int maxG = variant == 0 ? 4 : 8;
-  const int mpl_max = tab[ntab - 1];
-  int G = 1;
-  if (prefer_waves == 2 || prefer_waves == 4 || prefer_waves == 8) G = prefer_waves;
+  int G0 = 1;
+  if (prefer_waves == 2 || prefer_waves == 4 || prefer_waves == 8) G0 = prefer_waves;
   // The register-resident kernel is fastest with at most 32 states per lane (120 VGPRs: four waves per
   // SIMD), but the eighth wave of a target costs more than it brings: measured on MI355X, N=2000 is best with
   // 1 wave per target (6.6 ms), N=5008 with 4 x 20 words (97 ms; 2 x 40: 103), N=10000 with 4 x 40 (231 ms;
   // 8 x 20: 284).
   if (variant == 1 && prefer_waves == 0)
-    while (G < maxG && (M + G - 1) / G > (G >= 4 ? 40 : 32)) G *= 2;
-  if (G > maxG) G = maxG;
-  while (G < maxG && (M + G - 1) / G > mpl_max) G *= 2;
-  const int need = (M + G - 1) / G;
-  int MPL = 0;
-  for (int i = 0; i < ntab; i++)
-    if (tab[i] >= need) {
-      MPL = tab[i];
-      break;
+    while (G0 < maxG && (M + G0 - 1) / G0 > (G0 >= 4 ? 40 : 32)) G0 *= 2;
+  if (G0 > maxG) G0 = maxG;
+  // words per lane for G waves, 0 if that wave count cannot paint N states
+  auto fit = [&](int G) {
+    if (variant == 0) {
+      const int need = (M + G - 1) / G;
+      for (int m : kMplPlain)
+        if (m >= need) return m;
+      return 0;
     }
-  if (variant != 0 && G == 8 && MPL == 80) MPL = 0;  // stone staging would exceed the LDS of a CU
-  // the register-resident kernel reads G*MPL words of every row and needs the padding bits of all of them
-  if (variant == 1 && MPL > 0 && G * MPL > row_stride_words(N)) {
-    if (G > 1) return choose_geometry(N, G / 2, variant);
-    MPL = 0;
-  }
-  return {G, MPL};  // MPL == 0: N too large for this variant
+    const int mpl = regs_words_per_lane(M, G);
+    // the register-resident kernel reads G*MPL words of every row and needs the padding bits of all of them
+    return (variant == 1 && G * mpl > row_stride_words(N)) ? 0 : mpl;
+  };
+  // the wave count asked for or given by the rule; failing that fewer waves, then more
+  for (int G = G0; G >= 1; G /= 2)
+    if (const int mpl = fit(G)) return {G, mpl};
+  for (int G = 2 * G0; G <= maxG; G *= 2)
+    if (const int mpl = fit(G)) return {G, mpl};
+  return {G0, 0};  // MPL == 0: N too large for this variant
 }
 
 // Geometry for a launch of K targets: the rule of choose_geometry, unless a model of the launch says that

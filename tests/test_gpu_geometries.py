@@ -19,6 +19,10 @@ pytestmark = pytest.mark.gpu
     (4500, 100, 2, 33, 4),   # 4 x 20
     (2300, 200, 3, 34, 1),   # 1 x 36
     (10000, 60, 2, 35, 0),   # the automatic choice for a panel of 10 000: 4 x 40
+    (5600, 100, 2, 38, 0),   # 88 words of bits: no geometry is 88 words wide, the rows are padded to 96 (4 x 24)
+    (5600, 100, 2, 38, 1),   # one wave cannot hold 88 words: 2 x 48
+    (6500, 80, 2, 39, 0),    # 102 words, rows padded to 112 (4 x 28)
+    (6500, 80, 2, 39, 8),    # 8 x 16 words would run past the padded row: 4 x 28
 ])
 def test_geometry(N, L, W, seed, waves):
     seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=seed, r_mode="skew" if seed % 2 else "flat")
