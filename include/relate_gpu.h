@@ -44,7 +44,11 @@ size_t relate_record_bytes(int N);
  * Reads <output>/parameters_c<c>.bin and <output>/chunk_<c>.{hap,r}, writes
  * <output>/chunk_<c>/paint/relate_<w>.bin byte-compatible with the reference.
  * theta == NULL keeps Data's default 0.001 (src/data.cpp:97); rho == NULL
- * leaves r unscaled.  device < 0 shards the targets over every visible device.
+ * leaves r unscaled.  device < 0 shards the targets over every visible device
+ * (ranges of equal numbers of derived sites; the first device packs the matrix,
+ * the others receive the packed copy from it).  The files appear complete or
+ * not at all: records are written to relate_<w>.bin.part and renamed when every
+ * window is complete; on failure no relate_<w>.bin of this chunk is left.
  * ------------------------------------------------------------------------ */
 int relate_paint_chunk(const char* output_dir, int chunk_index, const double* theta, const double* rho, int device);
 
@@ -97,7 +101,12 @@ void relate_painter_free(relate_painter* p);
 /* ------------------------------------------------------------------------
  * 4. Device-resident plan: inputs and outputs stay in HBM (what the benchmark
  *    and the multi-GPU host drive; same algorithm and kernels as 1-3).
- *    Device pointers are passed as void*; `stream` is a hipStream_t or NULL.
+ *    Device pointers are passed as void*; `stream` is a hipStream_t, and NULL
+ *    means what it means in every HIP call: the default (null) stream, which is
+ *    also the handle a framework such as torch reports for its default stream.
+ *    Every call that takes a stream only enqueues work on it (exceptions are
+ *    stated); calls on one plan must be issued in order, on one stream or on
+ *    streams the caller orders itself.
  * ------------------------------------------------------------------------ */
 typedef struct relate_plan relate_plan;
 
@@ -169,6 +178,23 @@ int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* 
 int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, int pitch, const void* d_logscales,
                                 int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
                                 const double* weight_left, const double* weight_right, void* d_matrix, void* stream);
+/* nd_k of every haplotype of the loaded chunk (the number of sites its list holds: its derived sites and the
+ * two forced ends, src/fast_painting.cpp:60-110), N ints on the host; the cost of painting target k is
+ * proportional to it.  Waits for the result. */
+int relate_plan_derived_counts(relate_plan* p, int32_t* nd);
+/* Contiguous partition of N targets into `parts` ranges of (nearly) equal sums of nd: bounds[i] .. bounds[i+1]
+ * is range i, bounds has parts + 1 entries, bounds[0] = 0, bounds[parts] = N.  Host-only. */
+int relate_shard_by_work(int N, const int32_t* nd, int parts, int32_t* bounds);
+/* Paints targets [k_begin, k_end) of the loaded chunk and writes record k of window w at byte k *
+ * relate_record_bytes(N) of the open file fds[w] (pwrite; num_fds must equal the number of windows), i.e. the
+ * loop of pipeline/Paint.cpp:78-82 for a shard of the targets, whatever the order in which shards finish.
+ * Batches the targets to the free device memory and copies the records back through page-locked staging
+ * while host threads write them.  Returns when everything has been written. */
+int relate_plan_paint_to_files(relate_plan* p, double theta_painter, double theta_data, int k_begin, int k_end,
+                               const int* fds, int num_fds);
+/* Frees the page-locked staging block (at most 1 GiB) that the host-buffer and file entry points keep between
+ * calls; a no-op while a call is using it. */
+void relate_release_host_staging(void);
 /* Milliseconds of the last pack / prepare / paint, from HIP events on the stream they ran on
  * (blocks until the paint has finished); after relate_plan_repaint, ms_paint is the time of its two launches. */
 int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float* ms_paint);

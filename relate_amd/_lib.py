@@ -55,6 +55,10 @@ PROTOTYPES = {
     "relate_plan_repaint_layout": (C.c_int, [vp, C.c_int, i64p, C.POINTER(C.c_int), i64p]),
     "relate_plan_repaint": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "relate_plan_distance_matrix": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int64, i64p, u8p, f64p, f64p, vp, vp]),
+    "relate_plan_derived_counts": (C.c_int, [vp, i32p]),
+    "relate_shard_by_work": (C.c_int, [C.c_int, i32p, C.c_int, i32p]),
+    "relate_plan_paint_to_files": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "relate_release_host_staging": (None, []),
     "relate_plan_timings": (C.c_int, [vp, f32p, f32p, f32p]),
     "relate_plan_geometry": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "relate_fast_log": (C.c_int, [f32p, f32p, C.c_int, C.c_int]),

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <string>
 
 #include "../../include/relate_gpu.h"
@@ -43,8 +44,13 @@ int main(int argc, char** argv)
       fprintf(stderr, "--painting expects theta,rho\n");
       return 1;
     }
-    theta = (double)std::stof(painting.substr(0, comma));
-    rho = (double)std::stof(painting.substr(comma + 1));
+    try {
+      theta = (double)std::stof(painting.substr(0, comma));
+      rho = (double)std::stof(painting.substr(comma + 1));
+    } catch (const std::exception&) {  // std::invalid_argument / std::out_of_range
+      fprintf(stderr, "--painting expects two numbers, theta,rho (got \"%s\")\n", painting.c_str());
+      return 1;
+    }
     pt = &theta;
     pr = &rho;
   }

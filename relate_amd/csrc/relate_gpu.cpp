@@ -13,10 +13,13 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -169,9 +172,15 @@ struct relate_plan {
   std::vector<int32_t> h_bbj, h_bej;  // host copies of the stone indices, [K][W] (fetched when first asked for)
   HostBuf h_order;                    // launch order (int32); a member so that the asynchronous upload may outlive prepare
   bool stones_on_host = false;
-  hipStream_t prepare_stream = nullptr;
+  hipStream_t prepare_stream = nullptr;  // the null stream is a stream like any other: validity is a flag of its own
+  bool have_prepare_stream = false;
   DevBuf row_off, last_coef, last_nx, scratch;
   DevBuf dm_args;  // per-row arguments of the distance-matrix kernel
+  // page-locked staging of the small per-call arrays of repaint / distance_matrix: the upload is asynchronous, and
+  // the next call waits for `staged` (the upload alone, not the kernels behind it) before it refills the block
+  HostBuf h_stage;
+  hipEvent_t staged = nullptr;
+  bool stage_in_flight = false;
   HostBuf h_nd;   // int32 [K]
   HostBuf h_off;  // int64 [K]
   int64_t sum_nd = 0;
@@ -181,7 +190,10 @@ struct relate_plan {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool have_pack = false, have_prepare = false, have_paint = false;
 
-  hipStream_t pick(void* s) const { return s ? static_cast<hipStream_t>(s) : own_stream; }
+  // A NULL `stream` argument means what it means in every HIP call: the default (null) stream, which is also
+  // the handle torch reports for its default stream.  Work the library starts on its own behalf (host-buffer
+  // and file entry points) runs on own_stream and is waited for before those calls return.
+  hipStream_t pick(void* s) const { return static_cast<hipStream_t>(s); }
 };
 
 namespace {
@@ -200,6 +212,18 @@ int plan_set_chunk(relate_plan* p, int N, int L, int W, const int32_t* wb, hipSt
   HIP_TRY(hipMemcpyAsync(p->wb_dev.p, p->wb.data(), sizeof(int32_t) * (W + 1), hipMemcpyHostToDevice, st));
   p->K = 0;
   p->have_prepare = false;
+  return RELATE_OK;
+}
+
+// The staging block, at least `bytes` long, once the upload of the previous call has left it.
+int stage_block(relate_plan* p, size_t bytes, void** out)
+{
+  if (p->stage_in_flight) {
+    HIP_TRY(hipEventSynchronize(p->staged));
+    p->stage_in_flight = false;
+  }
+  if (int rc = p->h_stage.reserve(bytes)) return rc;
+  *out = p->h_stage.p;
   return RELATE_OK;
 }
 
@@ -233,6 +257,7 @@ int relate_plan_create(int device, relate_plan** out)
   p->device = device;
   hipError_t e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking);
   for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&p->ev[i]);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&p->staged, hipEventDisableTiming);
   if (e != hipSuccess) {
     relate_plan_destroy(p);
     return fail(RELATE_EGPU, std::string("stream/event creation: ") + hipGetErrorString(e));
@@ -250,7 +275,8 @@ void relate_plan_destroy(relate_plan* p)
   for (DevBuf* b : {&p->seq_own, &p->r_own, &p->wb_dev, &p->nd, &p->off, &p->dk, &p->coef, &p->nx, &p->bbj, &p->bej,
                     &p->order, &p->trace, &p->rec, &p->row_off, &p->last_coef, &p->last_nx, &p->scratch, &p->dm_args})
     b->release();
-  for (HostBuf* b : {&p->h_nd, &p->h_off, &p->h_order}) b->release();
+  for (HostBuf* b : {&p->h_nd, &p->h_off, &p->h_order, &p->h_stage}) b->release();
+  if (p->staged) (void)hipEventDestroy(p->staged);
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
@@ -402,7 +428,7 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   if (int rc = p->nd.reserve(sizeof(int32_t) * (size_t)K)) return rc;
   HIP_TRY(relate::launch_count_derived(p->d_cols, p->col_stride, p->L, k_begin, K, p->nd.as<int32_t>(), st));
   // the page-locked arrays below may still be feeding the uploads of an earlier prepare on another stream
-  if (p->prepare_stream && p->prepare_stream != st) HIP_TRY(hipStreamSynchronize(p->prepare_stream));
+  if (p->have_prepare_stream && p->prepare_stream != st) HIP_TRY(hipStreamSynchronize(p->prepare_stream));
   if (int rc = p->h_nd.reserve(sizeof(int32_t) * (size_t)K)) return rc;
   if (int rc = p->h_off.reserve(sizeof(int64_t) * (size_t)K)) return rc;
   if (int rc = p->h_order.reserve(sizeof(int32_t) * (size_t)K)) return rc;
@@ -450,6 +476,7 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   // indices are fetched by the first call that needs them (stone_indices_on_host).
   p->stones_on_host = false;
   p->prepare_stream = st;
+  p->have_prepare_stream = true;
   p->have_prepare = true;
   p->k_begin = k_begin;
   p->K = K;
@@ -548,18 +575,23 @@ int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* 
                         void* stream)
 {
   if (!p || !d_stones || !d_topology || !d_logscales) return fail(RELATE_EINVAL, "null argument");
-  std::vector<int64_t> ro((size_t)std::max(p->K, 0) + 1);
+  if (!p->have_prepare || p->K <= 0) return fail(RELATE_EINVAL, "no targets prepared");
+  HIP_TRY(hipSetDevice(p->device));
+  void* blk = nullptr;
+  if (int rc = stage_block(p, sizeof(int64_t) * ((size_t)p->K + 1), &blk)) return rc;
+  int64_t* ro = static_cast<int64_t*>(blk);
   int64_t rows = 0;
   int pitch = 0;
-  if (int rc = relate_plan_repaint_layout(p, window, &rows, &pitch, ro.data())) return rc;
-  HIP_TRY(hipSetDevice(p->device));
+  if (int rc = relate_plan_repaint_layout(p, window, &rows, &pitch, ro)) return rc;
   hipStream_t st = p->pick(stream);
   const int K = p->K;
   if (int rc = p->row_off.reserve(sizeof(int64_t) * (size_t)K)) return rc;
   if (int rc = p->last_coef.reserve(sizeof(double) * (size_t)K)) return rc;
   if (int rc = p->last_nx.reserve(sizeof(double) * (size_t)K)) return rc;
   if (int rc = p->scratch.reserve(sizeof(double) * (size_t)rows * pitch)) return rc;
-  HIP_TRY(hipMemcpyAsync(p->row_off.p, ro.data(), sizeof(int64_t) * (size_t)K, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(p->row_off.p, ro, sizeof(int64_t) * (size_t)K, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(p->staged, st));
+  p->stage_in_flight = true;
   const relate::PaintConsts c = make_consts(p->N, p->theta_p, p->theta_d);
   HIP_TRY(relate::launch_section_last_terms(p->dk.as<int32_t>(), p->off.as<int64_t>(), p->bej.as<int32_t>(), K, p->W,
                                             window, p->d_r, c, p->last_coef.as<double>(), p->last_nx.as<double>(), st));
@@ -592,8 +624,6 @@ int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* 
   HIP_TRY(relate::launch_repaint(a, p->geo_repaint, st));
   HIP_TRY(hipEventRecord(p->ev[5], st));
   p->have_paint = true;
-  // the row offsets were copied from a host vector that dies with this call
-  HIP_TRY(hipStreamSynchronize(st));
   return RELATE_OK;
 }
 
@@ -613,11 +643,13 @@ int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, i
   hipStream_t st = p->pick(stream);
   // one staging block: row indices, weights, flags
   const size_t nb = (size_t)N * (8 + 8 + 8) + (size_t)N;
-  std::vector<uint8_t> h(nb);
-  int64_t* hr = reinterpret_cast<int64_t*>(h.data());
-  double* hl = reinterpret_cast<double*>(h.data() + (size_t)8 * N);
-  double* hw = reinterpret_cast<double*>(h.data() + (size_t)16 * N);
-  uint8_t* hf = h.data() + (size_t)24 * N;
+  void* blk = nullptr;
+  if (int rc = stage_block(p, nb, &blk)) return rc;
+  uint8_t* h = static_cast<uint8_t*>(blk);
+  int64_t* hr = reinterpret_cast<int64_t*>(h);
+  double* hl = reinterpret_cast<double*>(h + (size_t)8 * N);
+  double* hw = reinterpret_cast<double*>(h + (size_t)16 * N);
+  uint8_t* hf = h + (size_t)24 * N;
   for (int n = 0; n < N; n++) {
     hr[n] = row_index[n];
     hl[n] = interpolate[n] ? weight_left[n] : 0.0;
@@ -625,7 +657,9 @@ int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, i
     hf[n] = interpolate[n] ? 1 : 0;
   }
   if (int rc = p->dm_args.reserve(nb)) return rc;
-  HIP_TRY(hipMemcpyAsync(p->dm_args.p, h.data(), nb, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(p->dm_args.p, h, nb, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(p->staged, st));
+  p->stage_in_flight = true;
   uint8_t* d = static_cast<uint8_t*>(p->dm_args.p);
   HIP_TRY(hipEventRecord(p->ev[4], st));
   HIP_TRY(relate::launch_distance_matrix(static_cast<const float*>(d_topology), pitch,
@@ -635,7 +669,6 @@ int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, i
                                          static_cast<float*>(d_matrix), st));
   HIP_TRY(hipEventRecord(p->ev[5], st));
   p->have_paint = true;
-  HIP_TRY(hipStreamSynchronize(st));  // the staging vector dies with this call
   return RELATE_OK;
 }
 
@@ -692,19 +725,11 @@ int relate_fast_log(const float* in, float* out, int n, int device)
 // --------------------------------------------------------------------------
 namespace {
 
-// Targets per batch so that the records of one batch stay under `budget` bytes of HBM.
-int batch_targets(int N, int W, size_t budget)
-{
-  const size_t per_target = relate_record_bytes(N) * (size_t)W;
-  size_t k = budget / std::max<size_t>(per_target, 1);
-  if (k < 1) k = 1;
-  if (k > (size_t)N) k = N;
-  return (int)k;
-}
-
 // Pinned staging memory for the copy back of the records.  Pinning a few hundred megabytes costs as much as
-// painting a chunk, so one block is kept for the life of the process and handed to one caller at a time
-// (a second concurrent caller pins a block of its own).
+// painting a chunk, so one block (at most kStagingBytes) is kept and handed to one caller at a time; a second
+// concurrent caller pins a block of its own and frees it when done.  relate_release_host_staging() frees the
+// kept block.
+constexpr size_t kStagingBytes = (size_t)1 << 30;
 struct PinnedCache {
   std::mutex m;
   void* p = nullptr;
@@ -725,8 +750,10 @@ struct PinnedLease {
           if (g_pinned.p) (void)hipHostFree(g_pinned.p);
           g_pinned.p = nullptr;
           g_pinned.bytes = 0;
-          if (hipHostMalloc(&g_pinned.p, bytes, hipHostMallocDefault) != hipSuccess)
-            return fail(RELATE_ENOMEM, "pinned host allocation failed");
+          if (hipHostMalloc(&g_pinned.p, bytes, hipHostMallocDefault) != hipSuccess) {
+            g_pinned.p = nullptr;
+            return fail(RELATE_ENOMEM, "pinned host allocation of " + std::to_string(bytes) + " bytes failed");
+          }
           g_pinned.bytes = bytes;
         }
         g_pinned.busy = true;
@@ -735,7 +762,10 @@ struct PinnedLease {
         return RELATE_OK;
       }
     }
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return fail(RELATE_ENOMEM, "pinned host allocation failed");
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+      p = nullptr;
+      return fail(RELATE_ENOMEM, "pinned host allocation of " + std::to_string(bytes) + " bytes failed");
+    }
     return RELATE_OK;
   }
   ~PinnedLease()
@@ -749,100 +779,249 @@ struct PinnedLease {
   }
 };
 
+// nd_k of targets [k_begin, k_end) of the loaded chunk, on the host.
+int derived_counts(relate_plan* p, int k_begin, int k_end, std::vector<int32_t>& nd)
+{
+  const int K = k_end - k_begin;
+  nd.resize((size_t)K);
+  DevBuf d;
+  if (int rc = d.reserve(sizeof(int32_t) * (size_t)K)) return rc;
+  hipError_t e = relate::launch_count_derived(p->d_cols, p->col_stride, p->L, k_begin, K, d.as<int32_t>(), p->own_stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(nd.data(), d.p, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, p->own_stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->own_stream);
+  d.release();
+  if (e != hipSuccess) return fail(RELATE_EGPU, std::string("count_derived: ") + hipGetErrorString(e));
+  return RELATE_OK;
+}
+
+// Contiguous partition of targets into `parts` ranges whose sums of nd (the number of sweeps a target costs)
+// are as equal as a contiguous split allows; every range is non-empty while there are targets left.
+void shard_by_work(const int32_t* nd, int N, int parts, int32_t* bounds)
+{
+  std::vector<int64_t> prefix((size_t)N + 1, 0);
+  for (int k = 0; k < N; k++) prefix[k + 1] = prefix[k] + std::max<int32_t>(nd[k], 0);
+  const int64_t total = prefix[N];
+  bounds[0] = 0;
+  for (int i = 1; i < parts; i++) {
+    const int64_t want = (int64_t)((__int128)total * i / parts);
+    int k = (int)(std::lower_bound(prefix.begin(), prefix.end(), want) - prefix.begin());
+    if (k > 0 && want - prefix[k - 1] <= prefix[k] - want) k--;  // the nearer of the two cuts
+    const int lo = std::min(N, bounds[i - 1] + 1), hi = std::max(lo, N - (parts - i));
+    bounds[i] = std::min(std::max(k, lo), hi);
+  }
+  bounds[parts] = N;
+}
+
+// Batches of consecutive targets: the records of a batch (W * R bytes per target) and its site lists (28 bytes
+// per derived site) stay under `budget` bytes of HBM, and one window's slab of records under `slab_cap` bytes.
+std::vector<int> plan_batches(const std::vector<int32_t>& nd, int k_begin, size_t R, int W, size_t budget, size_t slab_cap)
+{
+  std::vector<int> cuts{k_begin};
+  size_t bytes = 0, slab = 0;
+  for (size_t i = 0; i < nd.size(); i++) {
+    const size_t t = R * (size_t)W + (size_t)28 * (size_t)nd[i];
+    if (i > (size_t)(cuts.back() - k_begin) && (bytes + t > budget || slab + R > slab_cap)) {
+      cuts.push_back(k_begin + (int)i);
+      bytes = 0;
+      slab = 0;
+    }
+    bytes += t;
+    slab += R;
+  }
+  cuts.push_back(k_begin + (int)nd.size());
+  return cuts;
+}
+
 // sink(w, k0, nk, ptr): the records of targets [k0, k0+nk) of window w, contiguous at ptr (host memory).
+// The records come back window by window through a ring of pinned slots, and a few host threads hand each
+// window's slab to the sink as soon as it has arrived: the sink (a memcpy into pageable memory, or pwrite) is
+// slower than the link, and the slabs of different windows go to different places.
 template <class Sink>
 int paint_range(relate_plan* p, double theta_p, double theta_d, int k_begin, int k_end, Sink&& sink)
 {
   const int N = p->N, W = p->W;
   const size_t R = relate_record_bytes(N);
+  HIP_TRY(hipSetDevice(p->device));
+  std::vector<int32_t> nd;
+  if (int rc = derived_counts(p, k_begin, k_end, nd)) return rc;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  // records of a batch + 20 bytes per derived site for the lists; keep half of what is free
-  size_t budget = std::min<size_t>(free_b / 3, (size_t)24 << 30);
-  const int kb = batch_targets(N, W, budget);
-  DevBuf d_out;
-  const size_t batch_bytes = R * (size_t)W * (size_t)std::min(kb, k_end - k_begin);
-  if (int rc = d_out.reserve(batch_bytes)) return rc;
-  PinnedLease lease;
-  if (int rc = lease.acquire(batch_bytes)) {
-    d_out.release();
-    return rc;
-  }
-  void* h_out = lease.p;
+  size_t budget = std::min<size_t>(free_b / 2, (size_t)24 << 30);
+  const size_t slab_cap = std::max(kStagingBytes / 2, R);  // two slots at least (one target per slot at worst)
   int rc = RELATE_OK;
-  // The records come back window by window, and a few host threads hand each window's slab to the sink as soon
-  // as it has arrived: the sink (a memcpy into pageable memory, or pwrite) is slower than the link, and the slabs
-  // of different windows go to different places.
-  std::vector<hipEvent_t> arrived(W, nullptr);
-  for (int w = 0; w < W; w++) {
-    hipError_t e = hipEventCreateWithFlags(&arrived[w], hipEventDisableTiming);
+  DevBuf d_out;
+  std::vector<int> cuts;
+  // a refused allocation halves the budget and plans the batches again
+  for (int attempt = 0;; attempt++) {
+    cuts = plan_batches(nd, k_begin, R, W, budget, slab_cap);
+    int widest = 0;
+    for (size_t b = 0; b + 1 < cuts.size(); b++) widest = std::max(widest, cuts[b + 1] - cuts[b]);
+    rc = d_out.reserve(R * (size_t)W * (size_t)widest);
+    if (rc == RELATE_OK || attempt == 6 || widest == 1) break;
+    budget /= 2;
+  }
+  if (rc) return rc;
+  int widest = 0;
+  for (size_t b = 0; b + 1 < cuts.size(); b++) widest = std::max(widest, cuts[b + 1] - cuts[b]);
+  const size_t slot_bytes = R * (size_t)widest;
+  const int n_slots = (int)std::max<size_t>(2, std::min<size_t>((size_t)W, std::max<size_t>(kStagingBytes, 2 * slot_bytes) / slot_bytes));
+  PinnedLease lease;
+  if (int rc2 = lease.acquire(slot_bytes * (size_t)n_slots)) {
+    d_out.release();
+    return rc2;
+  }
+  uint8_t* h_ring = static_cast<uint8_t*>(lease.p);
+  std::vector<hipEvent_t> arrived(n_slots, nullptr);
+  for (int i = 0; i < n_slots; i++) {
+    hipError_t e = hipEventCreateWithFlags(&arrived[i], hipEventDisableTiming);
     if (e != hipSuccess) {
-      for (int v = 0; v < w; v++) (void)hipEventDestroy(arrived[v]);
+      for (int v = 0; v < i; v++) (void)hipEventDestroy(arrived[v]);
       d_out.release();
       return fail(RELATE_EGPU, std::string("hipEventCreate: ") + hipGetErrorString(e));
     }
   }
-  const int n_threads = std::min(4, W);
-  for (int k0 = k_begin; k0 < k_end && rc == RELATE_OK; k0 += kb) {
-    const int k1 = std::min(k_end, k0 + kb), nk = k1 - k0;
-    rc = relate_plan_prepare(p, theta_p, theta_d, k0, k1, nullptr, nullptr);
+  const int n_threads = std::min(4, std::min(W, n_slots));
+  for (size_t b = 0; b + 1 < cuts.size() && rc == RELATE_OK; b++) {
+    const int k0 = cuts[b], k1 = cuts[b + 1], nk = k1 - k0;
+    rc = relate_plan_prepare(p, theta_p, theta_d, k0, k1, nullptr, p->own_stream);
+    if (rc == RELATE_ENOMEM && nk > 1) {
+      // the site lists did not fit beside the records: split this batch
+      cuts.insert(cuts.begin() + (long)b + 1, k0 + nk / 2);
+      rc = RELATE_OK;
+      b--;
+      continue;
+    }
     if (rc) break;
-    rc = relate_plan_paint(p, d_out.p, nullptr);
+    rc = relate_plan_paint(p, d_out.p, p->own_stream);
     if (rc) break;
     const size_t slab = R * (size_t)nk;
-    hipError_t e = hipSuccess;
-    for (int w = 0; w < W && e == hipSuccess; w++) {
-      e = hipMemcpyAsync(static_cast<uint8_t*>(h_out) + (size_t)w * slab, static_cast<const uint8_t*>(d_out.p) + (size_t)w * slab,
-                         slab, hipMemcpyDeviceToHost, p->own_stream);
-      if (e == hipSuccess) e = hipEventRecord(arrived[w], p->own_stream);
-    }
-    if (e != hipSuccess) {
-      (void)hipStreamSynchronize(p->own_stream);
-      rc = fail(RELATE_EGPU, std::string("copy-back failed: ") + hipGetErrorString(e));
-      break;
-    }
+    // window w travels through slot w % n_slots: issued[w] once its copy is on the stream, drained[w] once the
+    // sink has returned (the slot may then take window w + n_slots)
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<char> issued((size_t)W, 0), drained((size_t)W, 0);
+    bool failed = false;
     std::vector<int> rcs(n_threads, RELATE_OK);
     std::vector<std::string> errs(n_threads);
     auto drain = [&](int ti) {
       if (hipSetDevice(p->device) != hipSuccess) {
         rcs[ti] = RELATE_EGPU;
         errs[ti] = "hipSetDevice failed in a copy-back thread";
-        return;
       }
-      for (int w = ti; w < W; w += n_threads) {
-        const hipError_t ew = hipEventSynchronize(arrived[w]);
+      for (int w = ti; w < W && rcs[ti] == RELATE_OK; w += n_threads) {
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return issued[w] || failed; });
+          if (failed) return;
+        }
+        const int slot = w % n_slots;
+        const hipError_t ew = hipEventSynchronize(arrived[slot]);
         if (ew != hipSuccess) {
           rcs[ti] = RELATE_EGPU;
           errs[ti] = std::string("painting or copy-back failed: ") + hipGetErrorString(ew);
-          return;
+        } else {
+          const int r = sink(w, k0, nk, h_ring + (size_t)slot * slot_bytes);
+          if (r != RELATE_OK) {
+            rcs[ti] = r;
+            errs[ti] = g_err;  // the sink's message lives in this thread
+          }
         }
-        const int r = sink(w, k0, nk, static_cast<const uint8_t*>(h_out) + (size_t)w * slab);
-        if (r != RELATE_OK) {
-          rcs[ti] = r;
-          errs[ti] = g_err;  // the sink's message lives in this thread
-          return;
-        }
+        std::lock_guard<std::mutex> lk(m);
+        drained[w] = 1;
+        if (rcs[ti] != RELATE_OK) failed = true;
+        cv.notify_all();
+      }
+      if (rcs[ti] != RELATE_OK) {
+        std::lock_guard<std::mutex> lk(m);
+        failed = true;
+        cv.notify_all();
       }
     };
-    if (n_threads == 1) {
-      drain(0);
-    } else {
-      std::vector<std::thread> th;
-      for (int ti = 0; ti < n_threads; ti++) th.emplace_back(drain, ti);
-      for (auto& t : th) t.join();
+    std::vector<std::thread> th;
+    for (int ti = 0; ti < n_threads; ti++) th.emplace_back(drain, ti);
+    hipError_t e = hipSuccess;
+    for (int w = 0; w < W && e == hipSuccess; w++) {
+      const int slot = w % n_slots;
+      if (w >= n_slots) {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return drained[w - n_slots] || failed; });
+        if (failed) break;
+      }
+      e = hipMemcpyAsync(h_ring + (size_t)slot * slot_bytes, static_cast<const uint8_t*>(d_out.p) + (size_t)w * slab, slab,
+                         hipMemcpyDeviceToHost, p->own_stream);
+      if (e == hipSuccess) e = hipEventRecord(arrived[slot], p->own_stream);
+      std::lock_guard<std::mutex> lk(m);
+      if (e == hipSuccess) issued[w] = 1;
+      else failed = true;
+      cv.notify_all();
     }
-    // the staging block is reused by the next batch: everything must have left the stream
+    for (auto& t : th) t.join();
+    // the ring and the device buffer are reused by the next batch: everything must have left the stream
     const hipError_t es = hipStreamSynchronize(p->own_stream);
+    if (e != hipSuccess) rc = fail(RELATE_EGPU, std::string("copy-back failed: ") + hipGetErrorString(e));
     for (int ti = 0; ti < n_threads; ti++)
       if (rcs[ti] != RELATE_OK && rc == RELATE_OK) rc = fail(rcs[ti], errs[ti]);
     if (es != hipSuccess && rc == RELATE_OK) rc = fail(RELATE_EGPU, std::string("painting or copy-back failed: ") + hipGetErrorString(es));
   }
-  for (int w = 0; w < W; w++) (void)hipEventDestroy(arrived[w]);
+  for (int i = 0; i < n_slots; i++) (void)hipEventDestroy(arrived[i]);
   d_out.release();
   return rc;
 }
 
+// pwrite of the whole buffer at `offset` (short writes continued)
+int pwrite_all(int fd, const uint8_t* src, size_t total, size_t offset, int w)
+{
+  size_t done = 0;
+  while (done < total) {
+    const ssize_t n = pwrite(fd, src + done, total - done, (off_t)(offset + done));
+    if (n <= 0) return fail(RELATE_EIO, "write to relate_" + std::to_string(w) + ".bin failed: " + std::strerror(errno));
+    done += (size_t)n;
+  }
+  return RELATE_OK;
+}
+
 }  // namespace
+
+extern "C" void relate_release_host_staging(void)
+{
+  std::lock_guard<std::mutex> lk(g_pinned.m);
+  if (g_pinned.busy || !g_pinned.p) return;
+  (void)hipHostFree(g_pinned.p);
+  g_pinned.p = nullptr;
+  g_pinned.bytes = 0;
+}
+
+extern "C" int relate_plan_derived_counts(relate_plan* p, int32_t* nd)
+{
+  if (!p || !nd) return fail(RELATE_EINVAL, "null argument");
+  if (!p->d_rows) return fail(RELATE_EINVAL, "no chunk loaded");
+  HIP_TRY(hipSetDevice(p->device));
+  std::vector<int32_t> v;
+  if (int rc = derived_counts(p, 0, p->N, v)) return rc;
+  std::memcpy(nd, v.data(), sizeof(int32_t) * v.size());
+  return RELATE_OK;
+}
+
+extern "C" int relate_shard_by_work(int N, const int32_t* nd, int parts, int32_t* bounds)
+{
+  if (N < 1 || parts < 1 || !nd || !bounds) return fail(RELATE_EINVAL, "bad argument");
+  shard_by_work(nd, N, parts, bounds);
+  return RELATE_OK;
+}
+
+extern "C" int relate_plan_paint_to_files(relate_plan* p, double theta_p, double theta_d, int k_begin, int k_end,
+                                          const int* fds, int num_fds)
+{
+  if (!p || !fds) return fail(RELATE_EINVAL, "null argument");
+  if (!p->d_rows) return fail(RELATE_EINVAL, "no chunk loaded");
+  if (num_fds != p->W) return fail(RELATE_EINVAL, "one file descriptor per window is needed");
+  if (k_begin < 0 || k_end > p->N || k_begin > k_end) return fail(RELATE_EINVAL, "bad target range");
+  if (k_begin == k_end) return RELATE_OK;
+  const size_t R = relate_record_bytes(p->N);
+  return paint_range(p, theta_p, theta_d, k_begin, k_end, [&](int w, int k0, int nk, const uint8_t* src) {
+    return pwrite_all(fds[w], src, (size_t)nk * R, (size_t)k0 * R, w);
+  });
+}
 
 extern "C" int relate_paint_stones(int N, int L, const uint8_t* seq, const double* r, double theta_p, double theta_d,
                                    int W, const int32_t* wb, int k_begin, int k_end, uint8_t* out, int device)
@@ -969,7 +1148,7 @@ int relate_painter_paint_stepping_stones(relate_painter* p, const relate_data* d
   if (!hit) {
     // paint a batch starting at k: the caller walks k upwards (src/pipelines.rs:179-194)
     const size_t budget = (size_t)2 << 30;
-    const int nk = std::min(d->N - k, batch_targets(d->N, (int)W, budget));
+    const int nk = (int)std::min<size_t>((size_t)(d->N - k), std::max<size_t>(1, budget / (R * std::max<size_t>(W, 1))));
     std::vector<uint8_t> rec((size_t)W * nk * R);
     int rc = relate_paint_stones(d->N, d->L, d->seq.data(), d->r.data(), p->theta, d->theta, (int)W, wb, k, k + nk,
                                  rec.data(), p->device);
@@ -997,6 +1176,88 @@ int relate_painter_paint_stepping_stones(relate_painter* p, const relate_data* d
 // --------------------------------------------------------------------------
 // Whole stage
 // --------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// The window files of one chunk while they are being written.  Consumers trust the size of relate_<w>.bin
+// (N records, src/anc_builder.cpp:65-69) and later stages delete their inputs, so a file must be complete or
+// absent: records go to relate_<w>.bin.part, which commit() renames once every record of every window has
+// been written; whatever is left uncommitted is unlinked.  Stale relate_<w>.bin of an earlier run are removed
+// at the start, as the reference's fopen(..., "wb") (pipeline/Paint.cpp:74) would have emptied them.
+struct WindowFiles {
+  std::vector<std::string> finals, parts;
+  std::vector<int> fds;
+  bool committed = false;
+  int open_all(const std::string& paint_dir, int W)
+  {
+    for (int w = 0; w < W; w++) {
+      finals.push_back(paint_dir + "/relate_" + std::to_string(w) + ".bin");
+      parts.push_back(finals.back() + ".part");
+      if (unlink(finals.back().c_str()) != 0 && errno != ENOENT) return fail(RELATE_EIO, "cannot remove stale " + finals.back());
+      const int fd = open(parts.back().c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+      if (fd < 0) return fail(RELATE_EIO, "cannot open " + parts.back() + ": " + std::strerror(errno));
+      fds.push_back(fd);
+    }
+    return RELATE_OK;
+  }
+  int commit()
+  {
+    int rc = RELATE_OK;
+    for (size_t w = 0; w < fds.size(); w++)
+      if (fds[w] >= 0) {
+        if (close(fds[w]) != 0 && rc == RELATE_OK) rc = fail(RELATE_EIO, "close of " + parts[w] + " failed");
+        fds[w] = -1;
+      }
+    for (size_t w = 0; w < parts.size() && rc == RELATE_OK; w++)
+      if (rename(parts[w].c_str(), finals[w].c_str()) != 0) rc = fail(RELATE_EIO, "cannot rename " + parts[w]);
+    if (rc != RELATE_OK) {
+      const std::string saved = g_err;
+      for (const std::string& f : finals) (void)unlink(f.c_str());  // some were renamed already: all or nothing
+      g_err = saved;
+      return rc;
+    }
+    committed = true;
+    return RELATE_OK;
+  }
+  ~WindowFiles()
+  {
+    const std::string saved = g_err;
+    for (int fd : fds)
+      if (fd >= 0) (void)close(fd);
+    if (!committed)
+      for (const std::string& f : parts) (void)unlink(f.c_str());
+    g_err = saved;
+  }
+};
+
+// Makes `p` (on another device) paint the chunk that `src` holds: the packed matrix and r travel from device
+// to device (8x smaller than the byte matrix, packed once), nothing is packed again.
+int plan_adopt_copy(relate_plan* p, const relate_plan* src)
+{
+  HIP_TRY(hipSetDevice(p->device));
+  const size_t bytes = rows_bytes(src) + cols_bytes(src);
+  if (p->packed_borrowed) {
+    p->packed = DevBuf();
+    p->packed_borrowed = false;
+  }
+  if (int rc = p->packed.reserve(bytes)) return rc;
+  if (int rc = p->r_own.reserve(sizeof(double) * (size_t)src->L)) return rc;
+  HIP_TRY(hipMemcpyPeerAsync(p->packed.p, p->device, src->d_rows, src->device, bytes, p->own_stream));
+  HIP_TRY(hipMemcpyPeerAsync(p->r_own.p, p->device, src->d_r, src->device, sizeof(double) * (size_t)src->L, p->own_stream));
+  if (int rc = plan_set_chunk(p, src->N, src->L, src->W, src->wb.data(), p->own_stream)) return rc;
+  HIP_TRY(hipStreamSynchronize(p->own_stream));
+  p->d_rows = p->packed.as<uint64_t>();
+  p->d_cols = reinterpret_cast<const uint64_t*>(static_cast<const char*>(p->packed.p) + rows_bytes(src));
+  p->d_r = p->r_own.as<double>();
+  p->have_pack = false;
+  return RELATE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int relate_paint_chunk(const char* output_dir, int chunk_index, const double* theta, const double* rho, int device)
 {
   if (!output_dir) return fail(RELATE_EINVAL, "null output directory");
@@ -1013,77 +1274,64 @@ int relate_paint_chunk(const char* output_dir, int chunk_index, const double* th
   if (int rc = relate_data_new((dir + "/chunk_" + c + ".hap").c_str(), nullptr, nullptr,
                                (dir + "/chunk_" + c + ".r").c_str(), nullptr, nullptr, 30000, 1.25e-8, &d))
     return rc;
-  if (d->N != N || d->L != L) {
-    relate_data_free(d);
-    return fail(RELATE_EINVAL, "parameters_c<c>.bin and chunk_<c>.hap disagree on N or L");
-  }
-  if (theta || rho) {
-    if (int rc = relate_data_set_painting(d, theta ? *theta : d->theta, rho ? *rho : 1.0)) {
-      relate_data_free(d);
-      return rc;
-    }
-  }
+  std::unique_ptr<relate_data, void (*)(relate_data*)> d_guard(d, relate_data_free);
+  if (d->N != N || d->L != L) return fail(RELATE_EINVAL, "parameters_c<c>.bin and chunk_<c>.hap disagree on N or L");
+  if (theta || rho)
+    if (int rc = relate_data_set_painting(d, theta ? *theta : d->theta, rho ? *rho : 1.0)) return rc;
   fprintf(stderr, "---------------------------------------------------------\n");
   fprintf(stderr, "Painting sequences...\n");  // pipeline/Paint.cpp:60-61
 
   const std::string chunk_dir = dir + "/chunk_" + c, paint_dir = chunk_dir + "/paint";
-  if ((mkdir(chunk_dir.c_str(), 0777) != 0 && errno != EEXIST) || (mkdir(paint_dir.c_str(), 0777) != 0 && errno != EEXIST)) {
-    relate_data_free(d);
+  if ((mkdir(chunk_dir.c_str(), 0777) != 0 && errno != EEXIST) || (mkdir(paint_dir.c_str(), 0777) != 0 && errno != EEXIST))
     return fail(RELATE_EIO, "cannot create " + paint_dir);
+  WindowFiles files;
+  if (int rc = files.open_all(paint_dir, W)) return rc;
+
+  // contiguous target ranges, one per device; every record has a fixed place k*R in its file
+  std::vector<int> devs;
+  if (device >= 0) devs.push_back(device);
+  else
+    for (int i = 0; i < ndev_all; i++) devs.push_back(i);
+  const int nd = (int)std::min<size_t>(devs.size(), (size_t)N);
+  // the first device packs; the others receive the packed matrix from it
+  relate_plan* first = nullptr;
+  if (int rc = relate_plan_create(devs[0], &first)) return rc;
+  std::unique_ptr<relate_plan, void (*)(relate_plan*)> first_guard(first, relate_plan_destroy);
+  if (int rc = relate_plan_load_host(first, N, L, d->seq.data(), d->r.data(), W, wb.data())) return rc;
+  std::vector<int32_t> bounds((size_t)nd + 1, 0);
+  bounds[nd] = N;
+  if (nd > 1) {
+    // ranges of equal work: the cost of a target is its number of derived sites
+    std::vector<int32_t> counts;
+    if (int rc = derived_counts(first, 0, N, counts)) return rc;
+    shard_by_work(counts.data(), N, nd, bounds.data());
   }
-  const size_t R = relate_record_bytes(N);
-  std::vector<int> fds(W, -1);
-  int rc = RELATE_OK;
-  for (int w = 0; w < W && rc == RELATE_OK; w++) {
-    const std::string name = paint_dir + "/relate_" + std::to_string(w) + ".bin";
-    fds[w] = open(name.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);  // "wb" in pipeline/Paint.cpp:74
-    if (fds[w] < 0) rc = fail(RELATE_EIO, "cannot open " + name);
-  }
-  if (rc == RELATE_OK) {
-    // contiguous target ranges, one per device; every record has a fixed place k*R in its file
-    std::vector<int> devs;
-    if (device >= 0) devs.push_back(device);
-    else
-      for (int i = 0; i < ndev_all; i++) devs.push_back(i);
-    const int nd = (int)std::min<size_t>(devs.size(), (size_t)N);
-    std::vector<int> rcs(nd, RELATE_OK);
-    std::vector<std::string> errs(nd);
-    auto work = [&](int i) {
-      const int k0 = (int)((int64_t)N * i / nd), k1 = (int)((int64_t)N * (i + 1) / nd);
-      relate_plan* p = nullptr;
-      int r = relate_plan_create(devs[i], &p);
-      if (!r) r = relate_plan_load_host(p, N, L, d->seq.data(), d->r.data(), W, wb.data());
-      if (!r)
-        r = paint_range(p, d->theta, d->theta, k0, k1, [&](int w, int kk0, int nk, const uint8_t* src) {
-          size_t done = 0;
-          const size_t total = (size_t)nk * R;
-          while (done < total) {
-            ssize_t n = pwrite(fds[w], src + done, total - done, (off_t)((size_t)kk0 * R + done));
-            if (n <= 0) return fail(RELATE_EIO, "write to relate_" + std::to_string(w) + ".bin failed");
-            done += (size_t)n;
-          }
-          return (int)RELATE_OK;
-        });
-      relate_plan_destroy(p);
-      rcs[i] = r;
-      errs[i] = g_err;
-    };
-    if (nd == 1) {
-      work(0);
-    } else {
-      std::vector<std::thread> th;
-      for (int i = 0; i < nd; i++) th.emplace_back(work, i);
-      for (auto& t : th) t.join();
+  std::vector<int> rcs(nd, RELATE_OK);
+  std::vector<std::string> errs(nd);
+  const double th = d->theta;
+  auto work = [&](int i) {
+    relate_plan* p = first;
+    int r = RELATE_OK;
+    if (i > 0) {
+      p = nullptr;
+      r = relate_plan_create(devs[i], &p);
+      if (!r) r = plan_adopt_copy(p, first);
     }
-    for (int i = 0; i < nd; i++)
-      if (rcs[i] != RELATE_OK && rc == RELATE_OK) rc = fail(rcs[i], errs[i]);
+    if (!r) r = relate_plan_paint_to_files(p, th, th, bounds[i], bounds[i + 1], files.fds.data(), W);
+    if (i > 0) relate_plan_destroy(p);
+    rcs[i] = r;
+    errs[i] = g_err;
+  };
+  if (nd == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> thr;
+    for (int i = 0; i < nd; i++) thr.emplace_back(work, i);
+    for (auto& t : thr) t.join();
   }
-  const std::string saved = g_err;
-  for (int w = 0; w < W; w++)
-    if (fds[w] >= 0 && close(fds[w]) != 0 && rc == RELATE_OK) rc = fail(RELATE_EIO, "close failed");
-  if (rc != RELATE_OK && !saved.empty()) g_err = saved;
-  relate_data_free(d);
-  return rc;
+  for (int i = 0; i < nd; i++)
+    if (rcs[i] != RELATE_OK) return fail(rcs[i], errs[i]);  // `files` unlinks the partial files
+  return files.commit();
 }
 
 }  // extern "C"

@@ -3,22 +3,37 @@
 
     rank 0 : reads chunk_<c>.hap / .r, uploads, bit-packs on its GPU
     all    : ONE broadcast of the packed matrix (+ r) from rank 0             <- the only exchange
-    rank g : paints targets [N*g/G, N*(g+1)/G) in batches, copies the records back over its own PCIe link and
-             writes them at their fixed place k*(56+8N) of relate_<w>.bin (pwrite), so that the files are
-             byte-identical to the ones a single process writes (pipeline/Paint.cpp:78-82 appends k = 0..N-1)
+    rank g : paints its range of targets -- ranges of equal numbers of derived sites, which every rank works
+             out for itself from the packed matrix it holds -- and writes the records at their fixed place
+             k*(56+8N) of relate_<w>.bin.part (pwrite), so that the files are byte-identical to the ones a
+             single process writes (pipeline/Paint.cpp:78-82 appends k = 0..N-1)
+    rank 0 : renames the .part files once every rank has reported success, and removes them otherwise:
+             a relate_<w>.bin exists only complete (consumers trust its size, src/anc_builder.cpp:65-69)
 
 The painting itself is delegated to a backend object (GpuBackend below drives the HIP library); the
 orchestration is independent of it, which is how the multi-process logic is tested on CPU with gloo."""
+import ctypes as C
 import os
 
 import numpy as np
 
-from ._lib import record_bytes
+from ._lib import i32p, lib, record_bytes
 
 
 def shard_range(N, rank, world):
-    """Contiguous target range of `rank`; the union over ranks is [0,N) and sizes differ by at most one."""
+    """Contiguous target range of `rank` by count; the union over ranks is [0,N) and sizes differ by at most one."""
     return (N * rank) // world, (N * (rank + 1)) // world
+
+
+def shard_by_work(nd, world):
+    """Bounds (world+1 ints) of contiguous target ranges with (nearly) equal sums of nd, the number of derived
+    sites of a target, to which the cost of painting it is proportional.  Host-only library routine."""
+    nd = np.ascontiguousarray(nd, dtype=np.int32)
+    bounds = np.zeros(world + 1, dtype=np.int32)
+    rc = lib().relate_shard_by_work(len(nd), nd.ctypes.data_as(i32p), world, bounds.ctypes.data_as(i32p))
+    if rc != 0:
+        raise ValueError("relate_shard_by_work: bad argument")
+    return bounds
 
 
 def read_parameters(output_dir, chunk_index):
@@ -41,7 +56,9 @@ def read_chunk(output_dir, chunk_index):
 
 
 class GpuBackend:
-    """Drives librelate_gpu.so on the rank's GPU; tensors are torch tensors on that device."""
+    """Drives librelate_gpu.so on the rank's GPU; tensors are torch tensors on that device.  Every library call
+    is given torch's current stream, so the packing, the broadcast (which torch orders on that stream) and the
+    kernels that read the broadcast matrix follow one another without host-side waits."""
 
     def __init__(self, device):
         import torch
@@ -51,12 +68,17 @@ class GpuBackend:
         self.plan = Plan(device)
         self.keep = []
 
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
     def packed_tensor(self, N, L):
-        from ._lib import lib
         return self.torch.empty(lib().relate_packed_bytes(N, L), dtype=self.torch.uint8, device=self.device)
 
     def r_tensor(self, L):
         return self.torch.empty(L, dtype=self.torch.float64, device=self.device)
+
+    def flag_tensor(self, value):
+        return self.torch.tensor([value], dtype=self.torch.int32, device=self.device)
 
     def pack(self, seq, r, wb, packed, d_r):
         """rank 0: upload the byte matrix and pack it into `packed`."""
@@ -64,36 +86,45 @@ class GpuBackend:
         L, N = seq.shape
         d_seq = t.from_numpy(np.ascontiguousarray(seq)).to(self.device)
         d_r.copy_(t.from_numpy(np.ascontiguousarray(r)))
-        st = t.cuda.current_stream(self.device).cuda_stream
-        self.plan.load_device_into(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, packed.data_ptr(), packed.numel(), st)
-        t.cuda.synchronize(self.device)
+        self.plan.load_device_into(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, packed.data_ptr(), packed.numel(),
+                                   self._stream())
+        t.cuda.current_stream(self.device).synchronize()  # d_seq is dropped on return
         self.keep = [packed, d_r]
 
     def adopt(self, N, L, wb, packed, d_r):
-        st = self.torch.cuda.current_stream(self.device).cuda_stream
-        self.plan.load_packed(N, L, packed.data_ptr(), packed.numel(), d_r.data_ptr(), wb, st)
+        self.plan.load_packed(N, L, packed.data_ptr(), packed.numel(), d_r.data_ptr(), wb, self._stream())
         self.keep = [packed, d_r]
+
+    def derived_counts(self):
+        self.torch.cuda.current_stream(self.device).synchronize()  # the library counts on a stream of its own
+        return self.plan.derived_counts()
 
     def paint(self, theta_p, theta_d, k0, k1):
         """Records of targets [k0,k1) as a (W, k1-k0, R) uint8 array on the host."""
         t = self.torch
-        st = t.cuda.current_stream(self.device).cuda_stream
+        st = self._stream()
         self.plan.prepare(theta_p, theta_d, k0, k1, st)
         out = t.empty(self.plan.out_bytes(), dtype=t.uint8, device=self.device)
         self.plan.paint(out.data_ptr(), st)
-        t.cuda.synchronize(self.device)
+        t.cuda.current_stream(self.device).synchronize()
         return out.cpu().numpy().reshape(self.plan.W, k1 - k0, record_bytes(self.plan.N))
 
+    def paint_to_files(self, theta_p, theta_d, k0, k1, fds):
+        """Paints [k0,k1) and writes the records at k*R of the open files `fds` (one per window): batching,
+        page-locked copy-back and the writing threads are the library's (relate_plan_paint_to_files)."""
+        self.torch.cuda.current_stream(self.device).synchronize()  # the library paints on a stream of its own
+        self.plan.paint_to_files(theta_p, theta_d, k0, k1, fds)
 
-def paint_chunk_distributed(output_dir, chunk_index, theta=None, rho=None, backend=None, batch_bytes=2 << 30):
+
+def paint_chunk_distributed(output_dir, chunk_index, theta=None, rho=None, backend=None, balance=True):
     """Paint stage of one chunk over all ranks of the default process group (initialise it first).
 
-    Returns the (k0, k1) range this rank painted."""
+    Returns the (k0, k1) range this rank painted.  Raises on every rank if any rank failed; no relate_<w>.bin of
+    the chunk exists then."""
     import torch.distributed as dist
     rank, world = dist.get_rank(), dist.get_world_size()
     N, L, wb = read_parameters(output_dir, chunk_index)
     W = len(wb) - 1
-    R = record_bytes(N)
     theta_v = 0.001 if theta is None else float(theta)  # Data's default, src/data.cpp:97
     packed = backend.packed_tensor(N, L)
     d_r = backend.r_tensor(L)
@@ -107,23 +138,42 @@ def paint_chunk_distributed(output_dir, chunk_index, theta=None, rho=None, backe
     if rank != 0:
         backend.adopt(N, L, wb, packed, d_r)
     paint_dir = os.path.join(str(output_dir), f"chunk_{chunk_index}", "paint")
+    finals = [os.path.join(paint_dir, f"relate_{w}.bin") for w in range(W)]
+    parts = [f + ".part" for f in finals]
     if rank == 0:
         os.makedirs(paint_dir, exist_ok=True)
-        for w in range(W):  # "wb" in pipeline/Paint.cpp:74: start from empty files
-            with open(os.path.join(paint_dir, f"relate_{w}.bin"), "wb"):
+        for f, p in zip(finals, parts):  # "wb" in pipeline/Paint.cpp:74: nothing of an earlier run survives
+            if os.path.exists(f):
+                os.unlink(f)
+            with open(p, "wb"):
                 pass
     dist.barrier()
-    k0, k1 = shard_range(N, rank, world)
-    fds = [os.open(os.path.join(paint_dir, f"relate_{w}.bin"), os.O_WRONLY) for w in range(W)]
+    if balance and world > 1:
+        bounds = shard_by_work(backend.derived_counts(), world)
+        k0, k1 = int(bounds[rank]), int(bounds[rank + 1])
+    else:
+        k0, k1 = shard_range(N, rank, world)
+    ok, err = 1, None
+    fds = []
     try:
-        kb = max(1, min(N, int(batch_bytes // max(1, W * R))))
-        for a in range(k0, k1, kb):
-            b = min(k1, a + kb)
-            rec = backend.paint(theta_v, theta_v, a, b)
-            for w in range(W):
-                os.pwrite(fds[w], rec[w].tobytes(), a * R)
+        fds = [os.open(p, os.O_WRONLY) for p in parts]
+        if k1 > k0:
+            backend.paint_to_files(theta_v, theta_v, k0, k1, fds)
+    except Exception as e:  # reported to every rank below
+        ok, err = 0, e
     finally:
         for fd in fds:
             os.close(fd)
+    flag = backend.flag_tensor(ok)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    all_ok = int(flag.item()) == 1
+    if rank == 0:
+        for f, p in zip(finals, parts):
+            if all_ok:
+                os.replace(p, f)
+            elif os.path.exists(p):
+                os.unlink(p)
     dist.barrier()
+    if not all_ok:
+        raise RuntimeError(f"painting of chunk {chunk_index} failed on rank {rank if err else '(another)'}: {err}")
     return k0, k1

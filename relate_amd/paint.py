@@ -169,6 +169,18 @@ class Plan:
                                                 wl.ctypes.data_as(f64p), wr.ctypes.data_as(f64p), vp(d_matrix),
                                                 vp(stream)))
 
+    def derived_counts(self):
+        """nd_k of every haplotype of the loaded chunk (int32 array of N)."""
+        nd = np.zeros(self.N, dtype=np.int32)
+        check(lib().relate_plan_derived_counts(self._h, nd.ctypes.data_as(i32p)))
+        return nd
+
+    def paint_to_files(self, theta_painter, theta_data, k_begin, k_end, fds):
+        """Paints [k_begin,k_end) and pwrite()s record k of window w at k*R of the open file descriptor fds[w]."""
+        arr = (C.c_int * len(fds))(*fds)
+        check(lib().relate_plan_paint_to_files(self._h, float(theta_painter), float(theta_data), k_begin, k_end, arr,
+                                               len(fds)))
+
     def timings(self):
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         check(lib().relate_plan_timings(self._h, C.byref(a), C.byref(b), C.byref(c)))

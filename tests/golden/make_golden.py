@@ -53,9 +53,38 @@ def save(name, seq, r, wb, tp, td, extra=None):
     print(name, out.shape, f"{out.nbytes/1e3:.0f} kB")
 
 
+def fast_log_inputs():
+    """Arguments for fast_log (src/fast_log.hpp:6-21): the decades of the reference's own test
+    (test/test_log.cpp:6-15), every power of ten and of two a float holds, the rescale thresholds the painting
+    feeds it (1e-10, 1e10), the neighbours of mantissa and exponent boundaries, zero, denormals, the largest
+    finite value, infinity, and seeded log-uniform random values."""
+    rng = np.random.default_rng(20)
+    parts = [
+        np.array([1e-4, 1e-3, 1e-2, 1e-1, 1.0, 1e1, 1e2, 1e3, 1e4], dtype=np.float32),
+        (10.0 ** np.arange(-45, 39, dtype=np.float64)).astype(np.float32),
+        (2.0 ** np.arange(-149, 128, dtype=np.float64)).astype(np.float32),
+        np.array([1e-10, 1e10, 9.99999e-11, 1.00001e10, 0.0, 1.17549435e-38, 1.17549421e-38, 1e-45, 3.4028235e38,
+                  np.inf, 0.5, 2.0, 3.0, 1.5, 0.75], dtype=np.float32),
+        np.exp(rng.uniform(np.log(1e-38), np.log(3e38), 60000)).astype(np.float32),
+        np.exp(rng.uniform(np.log(1e-12), np.log(1e12), 20000)).astype(np.float32),
+    ]
+    x = np.concatenate(parts)
+    edges = np.concatenate([np.nextafter(x[:400], np.float32(0)), np.nextafter(x[:400], np.float32(np.inf))])
+    return np.concatenate([x, edges[np.isfinite(edges)]]).astype(np.float32)
+
+
+def save_fast_log():
+    x = fast_log_inputs()
+    fl = ol.ref().fast_log
+    y = np.array([fl(float(v)) for v in x], dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, "fast_log.npz"), x_bits=x.view(np.uint32), y_bits=y.view(np.uint32))
+    print("fast_log", x.size, "values")
+
+
 def main():
     if not ol.ref_available():
         raise SystemExit("oracle/_ref/libpaint_ref.so missing: run `make -C oracle` where /root/reference exists")
+    save_fast_log()
     for name, (kw, tp, td) in CASES.items():
         seq, r, wb = sy.make_chunk(**kw)
         save(name, seq, r, wb, tp, td)

@@ -24,7 +24,7 @@ def test_one_rank_group_over_rccl(tmp_path):
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29600 + os.getpid() % 300}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
-        k0, k1 = paint_chunk_distributed(tmp_path, 0, theta=0.002, rho=1.25, backend=GpuBackend(0), batch_bytes=300000)
+        k0, k1 = paint_chunk_distributed(tmp_path, 0, theta=0.002, rho=1.25, backend=GpuBackend(0))
     finally:
         dist.destroy_process_group()
     assert (k0, k1) == (0, 75)
@@ -34,6 +34,7 @@ def test_one_rank_group_over_rccl(tmp_path):
         raw = np.fromfile(tmp_path / "chunk_0" / "paint" / f"relate_{w}.bin", dtype=np.uint8)
         assert raw.size == 75 * R
         compare_records(raw.reshape(1, 75, R), want[w:w + 1], 75, f"window {w}")
+    assert not [f for f in os.listdir(tmp_path / "chunk_0" / "paint") if f.endswith(".part")]
 
 
 def test_packed_matrix_adopted_by_a_second_plan():

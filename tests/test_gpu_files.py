@@ -1,0 +1,99 @@
+"""The window files appear complete or not at all (run with -m gpu).
+
+Consumers of relate_<w>.bin trust its size, N records (src/anc_builder.cpp:65-69), and later stages delete their
+inputs (pipeline/FindEquivalentBranches.cpp:43-60), so a run that fails half way must not leave a file of the full
+size with a hole in it.  The failure is injected from outside: the painting runs in a child process whose file-size
+limit (RLIMIT_FSIZE) is smaller than one window file, so a pwrite in the middle of the copy-back fails."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import synth_np as sy
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_failed_write_leaves_no_window_file(tmp_path):
+    import relate_amd as ra
+    seq, r, wb = sy.make_chunk(N=90, L=2500, W=5, seed=41, r_mode="flat")
+    ra.write_chunk(tmp_path, 0, seq, r, wb)
+    paint = tmp_path / "chunk_0" / "paint"
+    paint.mkdir(parents=True)
+    R = ra.record_bytes(90)
+    (paint / "relate_3.bin").write_bytes(b"\0" * (90 * R))  # a complete-looking file of an earlier run
+    child = textwrap.dedent(f"""
+        import resource, signal, sys
+        sys.path.insert(0, {ROOT!r})
+        import relate_amd as ra
+        ra.lib()
+        signal.signal(signal.SIGXFSZ, signal.SIG_IGN)
+        resource.setrlimit(resource.RLIMIT_FSIZE, ({90 * R // 2}, {90 * R // 2}))
+        try:
+            ra.paint_chunk({str(tmp_path)!r}, 0, 0.001, 1.0, device=0)
+        except ra.RelateError as e:
+            print("code", e.code, e)
+            sys.exit(7)
+        sys.exit(0)
+    """)
+    p = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 7, p.stdout + p.stderr
+    assert "code -2" in p.stdout  # RELATE_EIO
+    assert sorted(os.listdir(paint)) == [], "a failed run must leave neither relate_<w>.bin nor .part files"
+    # the same call without the limit writes all five files, and no .part file stays behind
+    ra.paint_chunk(tmp_path, 0, 0.001, 1.0, device=0)
+    assert sorted(os.listdir(paint)) == [f"relate_{w}.bin" for w in range(5)]
+    want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb)
+    for w in range(5):
+        raw = np.fromfile(paint / f"relate_{w}.bin", dtype=np.uint8)
+        assert raw.size == 90 * R
+        assert np.array_equal(ol.decode_records(raw.reshape(1, 90, R))["a_snp"], ol.decode_records(want[w:w + 1])["a_snp"])
+
+
+def test_unwritable_window_file_is_reported_and_nothing_is_left(tmp_path):
+    import relate_amd as ra
+    seq, r, wb = sy.make_chunk(N=40, L=600, W=3, seed=42, r_mode="flat")
+    ra.write_chunk(tmp_path, 0, seq, r, wb)
+    paint = tmp_path / "chunk_0" / "paint"
+    paint.mkdir(parents=True)
+    (paint / "relate_1.bin.part").mkdir()  # cannot be opened for writing
+    with pytest.raises(ra.RelateError) as e:
+        ra.paint_chunk(tmp_path, 0, 0.001, 1.0, device=0)
+    assert e.value.code == -2
+    assert sorted(os.listdir(paint)) == ["relate_1.bin.part"]
+
+
+def test_paint_to_files_of_a_shard_and_staging_release(tmp_path):
+    """relate_plan_paint_to_files: two shards of one chunk written through the library's copy-back into the same
+    files, the second first; then the page-locked staging block is released."""
+    import relate_amd as ra
+    from test_gpu_parity import compare_records
+    N, L, W = 300, 1500, 4
+    seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=43, r_mode="skew")
+    plan = ra.Plan(0)
+    plan.load_host(seq, r, wb)
+    nd = plan.derived_counts()
+    assert np.array_equal(nd, ol.count_derived(seq))
+    from relate_amd.dist import shard_by_work
+    b = shard_by_work(nd, 2)
+    R = ra.record_bytes(N)
+    fds = [os.open(tmp_path / f"relate_{w}.bin", os.O_WRONLY | os.O_CREAT, 0o666) for w in range(W)]
+    try:
+        plan.paint_to_files(0.001, 0.001, int(b[1]), N, fds)
+        plan.paint_to_files(0.001, 0.001, 0, int(b[1]), fds)
+    finally:
+        for fd in fds:
+            os.close(fd)
+    plan.close()
+    ra.lib().relate_release_host_staging()
+    want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb)
+    for w in range(W):
+        raw = np.fromfile(tmp_path / f"relate_{w}.bin", dtype=np.uint8)
+        assert raw.size == N * R
+        assert compare_records(raw.reshape(1, N, R), want[w:w + 1], N, f"shards, window {w}") == 0.0

@@ -1,0 +1,181 @@
+"""The benchmark configurations at their full length on the GPU: the 5008-haplotype chunk the benchmark times
+(N=5008, L=100 000, windows by the 5 GB rule: a few hundred), the rare-variant-dense 10 000-haplotype chunk with a
+skewed map (painted in batches of targets, as the benchmark does), and a 20 000-haplotype panel of several windows.
+
+The records stay in HBM (tens of gigabytes): every record's discrete fields are checked there against the window
+table and the haplotypes, the payloads for finiteness, sign and the zero at the target's own entry; sampled
+targets (first and last, around word edges, random ones) come back and are compared with the CPU oracle
+byte for byte on the discrete fields and to 1e-5 on the floats, with the share of floats that are not
+bit-identical recorded (gpurun_out/fullsize_bit_identity.txt) and bounded."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from test_gpu_parity import compare_records
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _note(line):
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "fullsize_bit_identity.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    print(line)
+
+
+def device_structure_checks(torch, out3, d_seq, wb, N, L, k_begin):
+    """out3: (W, K, R) uint8 cuda tensor of records of targets [k_begin, k_begin + K)."""
+    W, K, R = out3.shape
+    dev = out3.device
+    wb_t = torch.as_tensor(np.asarray(wb, dtype=np.int64), device=dev)
+    ks = torch.arange(k_begin, k_begin + K, device=dev)
+
+    def field(off, dtype):
+        return out3[:, :, off:off + 4].contiguous().view(dtype).reshape(W, K)
+
+    ob = 32 + 4 * N
+    start, end = field(0, torch.int32), field(4, torch.int32)
+    assert torch.equal(start, wb_t[:-1, None].expand(W, K).to(torch.int32))
+    assert torch.equal(end, (wb_t[1:, None] - 1).expand(W, K).to(torch.int32))
+    for base in (8, ob):  # block headers: uint64 1, uint64 N (src/collapsed_matrix.hpp:240-252)
+        assert bool((field(base, torch.int32) == 1).all()) and bool((field(base + 4, torch.int32) == 0).all())
+        assert bool((field(base + 8, torch.int32) == N).all()) and bool((field(base + 12, torch.int32) == 0).all())
+    a_snp, b_snp = field(24, torch.int32).long(), field(ob + 16, torch.int32).long()
+    assert bool((a_snp[0] == 0).all()) and bool((b_snp[W - 1] == L - 1).all())
+    # stones sit on sites of their target's list, on the right sides of the window edges
+    # (src/fast_painting.cpp:33-45,:73-82): alpha of window w before wb[w], beta of window w-1 at or after it
+    edge = wb_t[1:W, None]
+    assert bool((a_snp[1:] < edge).all()) and bool((b_snp[:-1] >= edge).all()) and bool((a_snp[1:] < b_snp[:-1]).all())
+    assert bool((a_snp <= b_snp).all())
+    der_a = d_seq[a_snp, ks[None, :].expand(W, K)] == ord("1")
+    der_b = d_seq[b_snp, ks[None, :].expand(W, K)] == ord("1")
+    assert bool((der_a | (a_snp == 0)).all()) and bool((der_b | (b_snp == L - 1)).all())
+    a_ls, b_ls = field(28, torch.float32), field(ob + 20, torch.float32)
+    assert bool(torch.isfinite(a_ls).all()) and bool(torch.isfinite(b_ls).all())
+    # payloads, a few windows at a time
+    step = max(1, int((1 << 30) // (K * 4 * N)))
+    for w0 in range(0, W, step):
+        w1 = min(W, w0 + step)
+        for off, is_beta in ((32, False), (ob + 24, True)):
+            v = out3[w0:w1, :, off:off + 4 * N].contiguous().view(torch.float32).reshape(w1 - w0, K, N)
+            assert bool(torch.isfinite(v).all()) and bool((v >= 0).all())
+            own = v[:, torch.arange(K, device=dev), ks]
+            if is_beta:  # beta stones taken at the last SNP hold 1 for every state (src/fast_painting.cpp:427-432)
+                last = b_snp[w0:w1] == L - 1
+                assert bool(((own == 0) | last).all()) and bool(((own == 1) | ~last).all())
+            else:
+                assert bool((own == 0).all())
+            del v
+
+
+def sampled_against_oracle(torch, out3, seq, r, wb, tp, td, k_begin, picks, tag, limit):
+    W, K, R = out3.shape
+    N = seq.shape[1]
+    worst = 0.0
+    for k in picks:
+        got = out3[:, k - k_begin].cpu().numpy().reshape(W, 1, R)
+        want = ol.oracle().paint_stones(seq, r, tp, td, wb, int(k), int(k) + 1)
+        worst = max(worst, compare_records(got, want, N, f"{tag} target {k}"))
+    _note(f"{tag}: {len(picks)} targets against the oracle, worst share of floats not bit-identical {worst:.3e}")
+    assert worst <= limit, f"{tag}: {worst:.2e} of a target's floats differ in the last bit"
+
+
+@pytest.mark.timeout(900)
+def test_c3_5008_haplotypes_full_chunk():
+    import torch
+    import relate_amd as ra
+    N, L = 5008, 100000
+    seq, r = ra.synth_chunk(N, L, 2)  # the chunk bench.py times
+    wb = ra.window_boundaries(seq, memory_gb=5.0)
+    W, R = len(wb) - 1, ra.record_bytes(N)
+    assert W > 100
+    d_seq = torch.from_numpy(seq).cuda()
+    d_r = torch.from_numpy(r).cuda()
+    out = torch.empty(W * N * R, dtype=torch.uint8, device="cuda")
+    plan = ra.Plan(0)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, st)
+    sum_nd = plan.prepare(0.001, 0.001, 0, N, st)
+    assert plan.geometry()["waves_per_target"] > 1
+    plan.paint(out.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert sum_nd == int(ol.count_derived(seq).sum())
+    out3 = out.view(W, N, R)
+    device_structure_checks(torch, out3, d_seq, wb, N, L, 0)
+    rng = np.random.default_rng(3)
+    picks = sorted(set([0, 1, 63, 64, 65, 1279, 1280, 2559, 2560, 3839, 3840, 4991, 4992, 5006, 5007]
+                       + [int(v) for v in rng.integers(0, N, 5)]))
+    sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, 0, picks, "c3 N=5008 L=100000", 1e-4)
+    # the Rust caller's two thetas on a few targets of the same chunk (two-row backward pass, many windows)
+    plan.prepare(0.001, 0.01, 2555, 2565, st)
+    plan.paint(out.data_ptr(), st)
+    torch.cuda.synchronize()
+    sampled_against_oracle(torch, out[: W * 10 * R].view(W, 10, R), seq, r, wb, 0.001, 0.01, 2555, [2555, 2559, 2560, 2564],
+                           "c3 two thetas", 1e-4)
+    plan.close()
+
+
+@pytest.mark.timeout(900)
+def test_c5_10000_haplotypes_skewed_map_in_batches():
+    import torch
+    import relate_amd as ra
+    N, L = 10000, 50000
+    seq, r = ra.synth_chunk(N, L, 2, skewed_map=True)
+    assert r.max() / r.min() > 1e4
+    wb = ra.window_boundaries(seq, memory_gb=5.0)
+    W, R = len(wb) - 1, ra.record_bytes(N)
+    d_seq = torch.from_numpy(seq).cuda()
+    d_r = torch.from_numpy(r).cuda()
+    kb = int(min(N, (96 << 30) // (W * R)))  # the benchmark's batches
+    assert (N + kb - 1) // kb >= 3
+    out = torch.empty(W * kb * R, dtype=torch.uint8, device="cuda")
+    plan = ra.Plan(0)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, st)
+    rng = np.random.default_rng(5)
+    for k0 in range(0, N, kb):
+        k1 = min(N, k0 + kb)
+        plan.prepare(0.001, 0.001, k0, k1, st)
+        plan.paint(out.data_ptr(), st)
+        torch.cuda.synchronize()
+        out3 = out[: W * (k1 - k0) * R].view(W, k1 - k0, R)
+        device_structure_checks(torch, out3, d_seq, wb, N, L, k0)
+        picks = sorted(set([k0, k1 - 1] + [int(v) for v in rng.integers(k0, k1, 2)]))
+        sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, k0, picks, f"c5 N=10000 batch from {k0}", 1e-4)
+    plan.close()
+
+
+@pytest.mark.timeout(600)
+def test_20000_haplotypes_several_windows():
+    """The width of the sharded configuration (eight waves per target) over a list of hundreds of sites and
+    several windows; a shard of 48 targets spread over the panel's words."""
+    import torch
+    import relate_amd as ra
+    N, L, W = 20000, 2400, 6
+    seq, r = ra.synth_chunk(N, L, 4)
+    wb = ra.synth.even_windows(L, W)
+    R = ra.record_bytes(N)
+    d_seq = torch.from_numpy(seq).cuda()
+    d_r = torch.from_numpy(r).cuda()
+    plan = ra.Plan(0)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, st)
+    for k0 in (0, 9990, N - 16):
+        K = 16
+        out = torch.empty(W * K * R, dtype=torch.uint8, device="cuda")
+        plan.prepare(0.001, 0.001, k0, k0 + K, st)
+        plan.paint(out.data_ptr(), st)
+        torch.cuda.synchronize()
+        out3 = out.view(W, K, R)
+        device_structure_checks(torch, out3, d_seq, wb, N, L, k0)
+        sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, k0, list(range(k0, k0 + K, 3)),
+                               f"N=20000 targets from {k0}", 1e-4)
+    plan.close()

@@ -136,3 +136,19 @@ def test_distance_oracle_against_numpy_restatement():
         want = vals - mn
         want[n] = 0.0
         assert np.array_equal(got[n].view(np.uint32), want.view(np.uint32)), n
+
+
+def test_fast_log_matches_reference_bits():
+    """oracle_fast_log against the bits the compiled reference produced (src/fast_log.hpp:6-21) for 80 000
+    arguments: decades (test/test_log.cpp:6-15), powers of two and ten, boundary neighbours, denormals, random."""
+    from conftest import load_fast_log_golden
+    x, y = load_fast_log_golden()
+    fl = ol.oracle().fast_log
+    got = np.array([fl(float(v)) for v in x], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), y.view(np.uint32))
+    if ol.ref_available():
+        rf = ol.ref().fast_log
+        again = np.array([rf(float(v)) for v in x[:5000]], dtype=np.float32)
+        assert np.array_equal(again.view(np.uint32), y[:5000].view(np.uint32))
+    ok = np.isfinite(x) & (x >= 1e-4) & (x <= 1e4)
+    assert np.max(np.abs(got[ok].astype(np.float64) - np.log(x[ok].astype(np.float64)))) < 0.007  # test/test_log.cpp:7
