@@ -178,6 +178,18 @@ int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* 
 int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, int pitch, const void* d_logscales,
                                 int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
                                 const double* weight_left, const double* weight_right, void* d_matrix, void* stream);
+/* relate_plan_distance_matrix for callers that cannot allocate: code under HIP graph capture, loops that ask
+ * for one matrix per tree, harnesses that forbid hipMalloc.  It has no counterpart in the reference (whose
+ * GetMatrix fills a host matrix in place); same arguments, same kernel and same result as the entry point above,
+ * without a plan.  The per-row arguments (25 bytes per row) are staged in a fixed array inside the library's
+ * code object, of which every GPU holds its own copy (900 KiB) until the process ends: N may be at most 36 864,
+ * larger values are refused with RELATE_ERANGE.  The call allocates nothing on the device or the host; it
+ * copies the four host arrays (pageable memory is fine) and launches on `stream`.  All calls on one GPU share
+ * that GPU's array: calls that overlap in time on one GPU (different streams, or threads) race; calls on one
+ * stream follow each other safely. */
+int relate_distance_matrix_noalloc(int device, int N, const void* d_topology, int pitch, const void* d_logscales,
+                                   int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
+                                   const double* weight_left, const double* weight_right, void* d_matrix, void* stream);
 /* nd_k of every haplotype of the loaded chunk (the number of sites its list holds: its derived sites and the
  * two forced ends, src/fast_painting.cpp:60-110), N ints on the host; the cost of painting target k is
  * proportional to it.  Waits for the result. */

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "relate_plan_repaint_layout": (C.c_int, [vp, C.c_int, i64p, C.POINTER(C.c_int), i64p]),
     "relate_plan_repaint": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "relate_plan_distance_matrix": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int64, i64p, u8p, f64p, f64p, vp, vp]),
+    "relate_distance_matrix_noalloc": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int64, i64p, u8p, f64p, f64p, vp, vp]),
     "relate_plan_derived_counts": (C.c_int, [vp, i32p]),
     "relate_shard_by_work": (C.c_int, [C.c_int, i32p, C.c_int, i32p]),
     "relate_plan_paint_to_files": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),

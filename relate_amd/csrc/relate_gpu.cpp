@@ -672,6 +672,81 @@ int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, i
   return RELATE_OK;
 }
 
+// --------------------------------------------------------------------------
+// The distance matrix for callers that cannot allocate (code under HIP graph capture, tight loops that ask
+// for a matrix per tree, harnesses that forbid hipMalloc).  relate_plan_distance_matrix stages its per-row
+// arguments in a device buffer and a page-locked host block that it allocates and grows; here they go into a
+// fixed array in the code object, one copy per GPU, of which the host keeps the address per device.
+// --------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+constexpr int kNoAllocMaxN = 36864;  // the widest panel the painting kernels take (8 waves x 72 words)
+constexpr size_t kNoAllocBytes = ((size_t)kNoAllocMaxN * 25 + 255) / 256 * 256;  // row index, two weights, flag per row
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of this device's copy of `scratch` (the device must be current).  In host code the array's name is
+// only a handle for the symbol, never an address a kernel can use.
+int scratch_address(int device, unsigned char** out)
+{
+  std::lock_guard<std::mutex> lk(g_scratch_mutex);
+  if (!g_scratch_ptr[device]) {
+    void* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) return fail(RELATE_EGPU, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    g_scratch_ptr[device] = ptr;
+  }
+  *out = static_cast<unsigned char*>(g_scratch_ptr[device]);
+  return RELATE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int relate_distance_matrix_noalloc(int device, int N, const void* d_topology, int pitch, const void* d_logscales,
+                                   int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
+                                   const double* weight_left, const double* weight_right, void* d_matrix, void* stream)
+{
+  if (!d_topology || !d_logscales || !row_index || !interpolate || !d_matrix) return fail(RELATE_EINVAL, "null argument");
+  if (N < 1 || pitch < N) return fail(RELATE_EINVAL, "bad matrix size or pitch");
+  if (N > kNoAllocMaxN)
+    return fail(RELATE_ERANGE, "relate_distance_matrix_noalloc takes at most " + std::to_string(kNoAllocMaxN) +
+                                   " rows (its argument array is fixed): use relate_plan_distance_matrix");
+  const int ndev = relate_device_count();
+  if (ndev <= 0) return fail(RELATE_EGPU, "no HIP device visible");
+  if (device < 0 || device >= ndev || device >= kMaxDevices) return fail(RELATE_EINVAL, "device index out of range");
+  bool any_mixed = false;
+  for (int n = 0; n < N; n++) {
+    any_mixed = any_mixed || interpolate[n];
+    if (row_index[n] < 0 || row_index[n] + (interpolate[n] ? 1 : 0) >= total_rows)
+      return fail(RELATE_EINVAL, "topology row index out of range");
+  }
+  if (any_mixed && (!weight_left || !weight_right)) return fail(RELATE_EINVAL, "interpolated rows need weights");
+  HIP_TRY(hipSetDevice(device));
+  unsigned char* d = nullptr;
+  if (int rc = scratch_address(device, &d)) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // four sections of this device's array: row indices, left weights, right weights, flags (the kernel reads a
+  // weight only where the flag is set, so the caller's arrays go in as they are)
+  const size_t n8 = sizeof(int64_t) * (size_t)N;
+  HIP_TRY(hipMemcpyAsync(d, row_index, n8, hipMemcpyHostToDevice, st));
+  if (any_mixed) {
+    HIP_TRY(hipMemcpyAsync(d + n8, weight_left, n8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + 2 * n8, weight_right, n8, hipMemcpyHostToDevice, st));
+  }
+  HIP_TRY(hipMemcpyAsync(d + 3 * n8, interpolate, (size_t)N, hipMemcpyHostToDevice, st));
+  HIP_TRY(relate::launch_distance_matrix(static_cast<const float*>(d_topology), pitch, static_cast<const float*>(d_logscales),
+                                         reinterpret_cast<const int64_t*>(d), d + 3 * n8,
+                                         reinterpret_cast<const double*>(d + n8), reinterpret_cast<const double*>(d + 2 * n8), N,
+                                         static_cast<float*>(d_matrix), st));
+  return RELATE_OK;
+}
+
 int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float* ms_paint)
 {
   if (!p) return fail(RELATE_EINVAL, "null plan");

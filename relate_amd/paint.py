@@ -192,6 +192,20 @@ class Plan:
         return {"waves_per_target": g.value, "states_per_lane": m.value}
 
 
+def distance_matrix_noalloc(device, N, d_topology, pitch, d_logscales, total_rows, row_index, interpolate, weight_left,
+                            weight_right, d_matrix, stream=0):
+    """relate_distance_matrix_noalloc: Plan.distance_matrix without a plan and without any allocation in the
+    library (N <= 36864).  The four per-row arrays must be contiguous numpy arrays of the right types already
+    (int64, uint8, float64, float64): nothing is converted or copied on the way in."""
+    for a, dt in ((row_index, np.int64), (interpolate, np.uint8), (weight_left, np.float64), (weight_right, np.float64)):
+        if a is not None and (a.dtype != dt or not a.flags.c_contiguous):
+            raise TypeError("per-row arguments must be contiguous arrays of int64 / uint8 / float64 / float64")
+    check(lib().relate_distance_matrix_noalloc(
+        device, N, vp(d_topology), pitch, vp(d_logscales), total_rows, row_index.ctypes.data_as(i64p),
+        interpolate.ctypes.data_as(u8p), None if weight_left is None else weight_left.ctypes.data_as(f64p),
+        None if weight_right is None else weight_right.ctypes.data_as(f64p), vp(d_matrix), vp(stream)))
+
+
 def fast_log(x, device=0):
     """GPU fast_log (src/fast_log.hpp:6-21) of a float32 array."""
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -24,6 +24,9 @@ def test_failed_write_leaves_no_window_file(tmp_path):
     import relate_amd as ra
     seq, r, wb = sy.make_chunk(N=90, L=2500, W=5, seed=41, r_mode="flat")
     ra.write_chunk(tmp_path, 0, seq, r, wb)
+    warm = tmp_path / "warm"
+    warm.mkdir()
+    ra.write_chunk(warm, 0, seq, r, wb)
     paint = tmp_path / "chunk_0" / "paint"
     paint.mkdir(parents=True)
     R = ra.record_bytes(90)
@@ -32,7 +35,8 @@ def test_failed_write_leaves_no_window_file(tmp_path):
         import resource, signal, sys
         sys.path.insert(0, {ROOT!r})
         import relate_amd as ra
-        ra.lib()
+        # a complete run elsewhere first: the HIP runtime writes files of its own while it loads the kernels
+        ra.paint_chunk({str(warm)!r}, 0, 0.001, 1.0, device=0)
         signal.signal(signal.SIGXFSZ, signal.SIG_IGN)
         resource.setrlimit(resource.RLIMIT_FSIZE, ({90 * R // 2}, {90 * R // 2}))
         try:

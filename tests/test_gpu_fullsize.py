@@ -113,13 +113,13 @@ def test_c3_5008_haplotypes_full_chunk():
     rng = np.random.default_rng(3)
     picks = sorted(set([0, 1, 63, 64, 65, 1279, 1280, 2559, 2560, 3839, 3840, 4991, 4992, 5006, 5007]
                        + [int(v) for v in rng.integers(0, N, 5)]))
-    sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, 0, picks, "c3 N=5008 L=100000", 1e-4)
+    sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, 0, picks, "c3 N=5008 L=100000", 0.0)
     # the Rust caller's two thetas on a few targets of the same chunk (two-row backward pass, many windows)
     plan.prepare(0.001, 0.01, 2555, 2565, st)
     plan.paint(out.data_ptr(), st)
     torch.cuda.synchronize()
     sampled_against_oracle(torch, out[: W * 10 * R].view(W, 10, R), seq, r, wb, 0.001, 0.01, 2555, [2555, 2559, 2560, 2564],
-                           "c3 two thetas", 1e-4)
+                           "c3 two thetas", 0.0)
     plan.close()
 
 
@@ -149,7 +149,7 @@ def test_c5_10000_haplotypes_skewed_map_in_batches():
         out3 = out[: W * (k1 - k0) * R].view(W, k1 - k0, R)
         device_structure_checks(torch, out3, d_seq, wb, N, L, k0)
         picks = sorted(set([k0, k1 - 1] + [int(v) for v in rng.integers(k0, k1, 2)]))
-        sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, k0, picks, f"c5 N=10000 batch from {k0}", 1e-4)
+        sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, k0, picks, f"c5 N=10000 batch from {k0}", 0.0)
     plan.close()
 
 
@@ -177,5 +177,5 @@ def test_20000_haplotypes_several_windows():
         out3 = out.view(W, K, R)
         device_structure_checks(torch, out3, d_seq, wb, N, L, k0)
         sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, k0, list(range(k0, k0 + K, 3)),
-                               f"N=20000 targets from {k0}", 1e-4)
+                               f"N=20000 targets from {k0}", 0.0)
     plan.close()

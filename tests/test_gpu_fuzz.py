@@ -3,7 +3,7 @@
 The fixed cases of test_gpu_parity.py pin the shapes the reference's own tests use; this sweep walks
 the corners between them: N around multiples of 64, very short lists, one window, sub-ranges of
 targets, one theta and two, every wave count, flat and skewed recombination maps.  Same bar:
-discrete fields bit-exact, floats within 1e-5 relative."""
+discrete fields bit-exact, floats within 1e-5 relative -- and, as measured on every case here, bit-identical."""
 import numpy as np
 import pytest
 
@@ -47,4 +47,4 @@ def test_random_configuration(N, L, W, seed, mode, tp, td, waves, k0, k1):
     want = ol.oracle().paint_stones(seq, r, tp, td, wb, k0, k1)
     got = gpu_paint(seq, r, tp, td, wb, 1, waves, k0, k1)
     frac = compare_records(got, want, N, f"N={N} L={L} W={W} {mode} thetas {tp},{td} waves {waves} k [{k0},{k1})")
-    assert frac < 1e-3
+    assert frac == 0.0

@@ -28,10 +28,10 @@ def test_geometry(N, L, W, seed, waves):
     seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=seed, r_mode="skew" if seed % 2 else "flat")
     want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb, 0, 64)
     got = gpu_paint(seq, r, 0.001, 0.001, wb, 1, waves, 0, 64)
-    assert compare_records(got, want, N, f"N={N} waves={waves}") < 1e-4
+    assert compare_records(got, want, N, f"N={N} waves={waves}") == 0.0
     want = ol.oracle().paint_stones(seq, r, 0.001, 0.01, wb, 100, 130)
     got = gpu_paint(seq, r, 0.001, 0.01, wb, 1, waves, 100, 130)
-    assert compare_records(got, want, N, f"N={N} waves={waves}, two thetas") < 1e-4
+    assert compare_records(got, want, N, f"N={N} waves={waves}, two thetas") == 0.0
 
 
 def test_automatic_choice_counts_rounds():
@@ -50,4 +50,4 @@ def test_automatic_choice_counts_rounds():
     plan.close()
     want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb, 0, N)
     got = gpu_paint(seq, r, 0.001, 0.001, wb, 1, 0, 0, N)
-    assert compare_records(got, want, N, "N=3000, all targets, automatic geometry") < 1e-4
+    assert compare_records(got, want, N, "N=3000, all targets, automatic geometry") == 0.0

@@ -133,7 +133,7 @@ def test_against_oracle(N, L, W, seed, mode, tp, td, waves):
     want = ol.oracle().paint_stones(seq, r, tp, td, wb)
     got = gpu_paint(seq, r, tp, td, wb, 1, waves)
     frac = compare_records(got, want, N, f"N={N} L={L}")
-    assert frac < 1e-4
+    assert frac == 0.0  # measured: every stored float equals the oracle's (gpurun_out/bit_identity_tests.txt)
 
 
 def test_full_size_sampled_targets_and_structure():
@@ -164,7 +164,7 @@ def test_full_size_sampled_targets_and_structure():
     for k in picks:
         want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb, int(k), int(k) + 1)
         fracs.append(compare_records(got[:, k:k + 1], want, N, f"target {k}"))
-    assert max(fracs) < 1e-3
+    assert max(fracs) == 0.0
 
 
 def test_paint_chunk_files_and_ffi_mirror(tmp_path):
