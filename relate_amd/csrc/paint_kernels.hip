@@ -555,7 +555,7 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
   // SIMD), but the eighth wave of a target costs more than it brings: measured on MI355X, N=2000 is best with
   // 1 wave per target (6.6 ms), N=5008 with 4 x 20 words (97 ms; 2 x 40: 103), N=10000 with 4 x 40 (231 ms;
   // 8 x 20: 284).
-  if (variant == 1 && prefer_waves == 0)
+  if (variant >= 1 && prefer_waves == 0)
     while (G0 < maxG && (M + G0 - 1) / G0 > (G0 >= 4 ? 40 : 32)) G0 *= 2;
   if (G0 > maxG) G0 = maxG;
   // words per lane for G waves, 0 if that wave count cannot paint N states
@@ -568,7 +568,7 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
     }
     const int mpl = regs_words_per_lane(M, G);
     // the register-resident kernel reads G*MPL words of every row and needs the padding bits of all of them
-    return (variant == 1 && G * mpl > row_stride_words(N)) ? 0 : mpl;
+    return (variant >= 1 && G * mpl > row_stride_words(N)) ? 0 : mpl;
   };
   // the wave count asked for or given by the rule; failing that fewer waves, then more
   for (int G = G0; G >= 1; G /= 2)
@@ -642,7 +642,7 @@ double launch_cost(PaintGeometry g, int K)
 PaintGeometry choose_geometry_for_launch(int N, int K, int prefer_waves, int variant)
 {
   const PaintGeometry rule = choose_geometry(N, prefer_waves, variant);
-  if (variant != 1 || prefer_waves != 0 || rule.MPL <= 0 || K <= 0) return rule;
+  if (variant < 1 || prefer_waves != 0 || rule.MPL <= 0 || K <= 0) return rule;
   if (N > 5120) return rule;  // beyond the sizes the constants were fitted on
   PaintGeometry best = rule;
   double best_cost = 0.93 * launch_cost(rule, K);

@@ -413,7 +413,7 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   p->geo = relate::choose_geometry_for_launch(p->N, K, p->prefer_waves, p->variant);
   if (p->geo.MPL <= 0) return fail(RELATE_ERANGE, "N is too large for the selected kernel variant");
   p->geo_repaint = relate::choose_geometry(p->N, p->prefer_waves, p->variant);  // one window per launch: its own rule below
-  if (p->variant == 1 && p->prefer_waves == 0) {
+  if (p->variant >= 1 && p->prefer_waves == 0) {
     // one window of K targets should fill most of the 4096 wave slots of the chip (4 per SIMD); measured on
     // C2 (K = 2000): 2 waves per target 4.8 ms, 1 wave 5.9 ms, 4 waves 5.3 ms
     while (p->geo_repaint.G < 8 && (long long)K * p->geo_repaint.G < 3072) {
@@ -453,7 +453,7 @@ int relate_plan_prepare(relate_plan* p, double theta_p, double theta_d, int k_be
   if (int rc = p->off.reserve(sizeof(int64_t) * (size_t)K)) return rc;
   if (int rc = p->order.reserve(sizeof(int32_t) * (size_t)K)) return rc;
   if (int rc = p->dk.reserve(sizeof(int32_t) * (size_t)total)) return rc;
-  const bool records = p->variant == 1;  // the register-resident kernel reads interleaved site records
+  const bool records = p->variant >= 1;  // the register-resident kernels read interleaved site records
   if (records) {
     if (int rc = p->rec.reserve(sizeof(relate::SiteRec) * (size_t)total)) return rc;
   } else {
@@ -515,7 +515,7 @@ int relate_plan_paint(relate_plan* p, void* d_out, void* stream)
   a.trace = nullptr;
   // Diagnostics: RELATE_TRACE=<file> makes the register-resident kernel record, per workgroup, where it
   // ran and when it started and ended (4 x u64: hardware id, start, end in 100 MHz ticks, pass | nd << 8).
-  const char* trace_path = p->variant == 1 ? std::getenv("RELATE_TRACE") : nullptr;
+  const char* trace_path = p->variant >= 1 ? std::getenv("RELATE_TRACE") : nullptr;
   const size_t trace_words = (size_t)8 * p->K;
   if (trace_path && *trace_path) {
     if (int rc = p->trace.reserve(sizeof(uint64_t) * trace_words)) return rc;

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Build-time check of the register-resident recursion kernels (relate_amd/csrc/paint_regs.hpp).
 
-The kernels keep their state in VGPRs >= 48 and their row buffers and fixed scalars in SGPRs >= 52, addressed by number
-from inline asm, and rely on the compiler staying below those limits.  This script reads the device
+The kernels keep their state and their row buffers and fixed scalars in registers addressed by number from inline
+asm (paint_regs.hpp: v48+ / s52+; paint_loop.hpp: v24+ / s24+), and rely on the compiler staying below those limits.  This script reads the device
 assembly (hipcc -S --cuda-device-only) of the instantiation files and fails if any instruction the
 COMPILER emitted (i.e. outside the asm statements) inside a paint_kernel_r / repaint_kernel_r kernel names v48+ or s52+.
 
@@ -11,7 +11,8 @@ COMPILER emitted (i.e. outside the asm statements) inside a paint_kernel_r / rep
 import re
 import sys
 
-V_LIMIT, S_LIMIT = 48, 52
+# first reserved VGPR / SGPR per kernel family (namespace of the mangled name)
+LIMITS = {"regs": (48, 52), "aloop": (24, 24)}
 REG = re.compile(r"\b([vs])(\d+)\b|\b([vs])\[(\d+):(\d+)\]")
 
 
@@ -21,9 +22,10 @@ def check(path):
     in_asm = False
     counts = {}
     for ln, line in enumerate(open(path), 1):
-        m = re.match(r"^(_ZN6relate4regs\d+(?:paint|repaint)_kernel_r\w+):", line)
+        m = re.match(r"^(_ZN6relate\d+(regs|aloop)\d+(?:paint|repaint)_kernel_[ra]\w+):", line)
         if m:
             kernel = m.group(1)
+            v_limit, s_limit = LIMITS[m.group(2)]
             counts[kernel] = 0
             continue
         if line.startswith("\t.end_amdhsa_kernel") or ".Lfunc_end" in line:
@@ -45,7 +47,7 @@ def check(path):
                 cls, hi = r.group(1), int(r.group(2))
             else:
                 cls, hi = r.group(3), int(r.group(5))
-            if hi >= (V_LIMIT if cls == "v" else S_LIMIT):
+            if hi >= (v_limit if cls == "v" else s_limit):
                 bad.append(f"{path}:{ln}: {kernel[:60]}: {code.strip()}")
     return counts, bad
 
