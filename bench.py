@@ -5,12 +5,16 @@
 
 A step is one complete Paint of one chunk whose inputs (the '0'/'1' haplotype matrix and r) already lie in
 HBM: bit-packing + transpose, per-target precompute, forward/backward recursion of all N targets, records
-written to HBM in their file layout.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank paints a chunk of its own of the same shape -- chunks are independent, which is also how the reference
-itself is parallelised (one process per --chunk_index, pipeline/Relate.cpp:217-229) -- so the per-GPU work is
-fixed ("weak") and the data path has no collective; the barrier around the timed region runs over RCCL.
+written to HBM in their file layout.
 
-Prints ONE JSON line (rank 0).  value = N(N-1)L cell-updates per second summed over all ranks.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the job still paints ONE chunk per step: the
+inputs lie in rank 0's HBM, rank 0 packs, the packed matrix (and r) is broadcast once over RCCL, every rank
+paints a contiguous range of targets holding 1/N of the derived sites and keeps its records in its own HBM.
+Total work is fixed ("strong" scaling); there is no reduction.  --independent-chunks gives every rank a chunk
+of its own instead (how the reference itself uses several processes, one per --chunk_index,
+pipeline/Relate.cpp:217-229; "weak").
+
+Prints ONE JSON line (rank 0).  value = N(N-1)L cell-updates per second of the whole job.
 """
 import argparse
 import json
@@ -157,6 +161,10 @@ def main():
                     help="also time the re-painting (RePaintSection of all targets) of window W; adds a 'repaint' object")
     ap.add_argument("--theta-data", type=float, default=0.0,
                     help="Data::theta when it differs from the painter's 0.001 (experiments: the Rust caller's two thetas)")
+    ap.add_argument("--sharded", action="store_true",
+                    help="paint ONE chunk with its targets sharded over the ranks (the default when --gpus > 1)")
+    ap.add_argument("--independent-chunks", action="store_true",
+                    help="with --gpus > 1: one chunk of the same shape per rank instead (no broadcast)")
     ap.add_argument("--N", type=int, default=0, help="override the number of haplotypes (experiments)")
     ap.add_argument("--L", type=int, default=0, help="override the number of SNPs (experiments)")
     args = ap.parse_args()
@@ -173,9 +181,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the painting path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # --sharded on one GPU, not under torch.distributed.run: a group of one rank
+            os.environ.setdefault("MASTER_PORT", str(29650 + os.getpid() % 300))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     N, L, desc = WORKLOADS[args.workload]
@@ -184,33 +196,64 @@ def main():
         desc = f"custom {N} haplotypes x {L} SNPs"
     theta = 0.001
     theta_data = args.theta_data if args.theta_data > 0 else theta
-    seq, r = ra.synth_chunk(N, L, seed=2 + rank, skewed_map=(args.workload == "c5"))
-    wb = ra.window_boundaries(seq, memory_gb=5.0)
+    sharded = (world > 1 and not args.independent_chunks) or args.sharded
+    # One chunk for the whole job (its targets sharded over the ranks), or -- the reference's own way of using
+    # several processes, one per --chunk_index -- a chunk of the same shape per rank.
+    seq = r = wb = None
+    if not sharded or rank == 0:
+        seq, r = ra.synth_chunk(N, L, seed=2 + (0 if sharded else rank), skewed_map=(args.workload == "c5"))
+        wb = ra.window_boundaries(seq, memory_gb=5.0)
+    if sharded and world > 1:
+        box = [wb]
+        dist.broadcast_object_list(box, src=0)
+        wb = box[0]
     W = len(wb) - 1
     R = ra.record_bytes(N)
-
-    d_seq = torch.from_numpy(seq).cuda()
-    d_r = torch.from_numpy(r).cuda()
-    # All stones of the chunk stay in HBM when they fit; otherwise the targets are painted in batches into
-    # one buffer (as relate_paint_chunk does before it writes each batch to the files).
-    budget = 96 << 30
-    kb = max(1, min(N, budget // (W * R)))
-    bufs = {"out": torch.empty(W * kb * R, dtype=torch.uint8, device="cuda")}  # dropped before the end-to-end leg
     stream = torch.cuda.current_stream().cuda_stream
-    plan = ra.Plan(local_rank, args.variant, args.waves)
     kern = {"pack_ms": 0.0, "prepare_ms": 0.0, "paint_ms": 0.0}
+    bufs = {}
+    plan = None
+    shard = None
 
-    def step():
-        plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, stream)
-        s = 0
-        for k0 in range(0, N, kb):
-            s += plan.prepare(theta, theta_data, k0, min(N, k0 + kb), stream)
-            plan.paint(bufs["out"].data_ptr(), stream)
-            t = plan.timings()  # HIP events recorded on the launch stream around each stage
-            kern["prepare_ms"] += t["prepare_ms"]
-            kern["paint_ms"] += t["paint_ms"]
-        kern["pack_ms"] += t["pack_ms"]
-        return s
+    if sharded:
+        from relate_amd.dist import GpuBackend, ShardedChunk
+        be = GpuBackend(local_rank)
+        be.plan.close()
+        be.plan = ra.Plan(local_rank, args.variant, args.waves)
+        plan = be.plan
+        d_seq = torch.from_numpy(seq).cuda() if rank == 0 else None
+        d_r = torch.from_numpy(r).cuda() if rank == 0 else None
+        shard = ShardedChunk(be, N, L, wb, theta, theta_data)
+        kern.update({"broadcast_ms": 0.0, "shard_ms": 0.0})
+
+        def step():
+            s = shard.step(d_seq, d_r)
+            kern["pack_ms"] += shard.last["pack"]
+            kern["broadcast_ms"] += shard.last["broadcast"]
+            kern["shard_ms"] += shard.last["shard"]
+            kern["paint_ms"] += shard.last["paint"]  # prepare + recursion of this rank's range
+            return s
+    else:
+        d_seq = torch.from_numpy(seq).cuda()
+        d_r = torch.from_numpy(r).cuda()
+        # All stones of the chunk stay in HBM when they fit; otherwise the targets are painted in batches into
+        # one buffer (as relate_paint_chunk does before it writes each batch to the files).
+        budget = 96 << 30
+        kb = max(1, min(N, budget // (W * R)))
+        bufs["out"] = torch.empty(W * kb * R, dtype=torch.uint8, device="cuda")  # dropped before the end-to-end leg
+        plan = ra.Plan(local_rank, args.variant, args.waves)
+
+        def step():
+            plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, stream)
+            s = 0
+            for k0 in range(0, N, kb):
+                s += plan.prepare(theta, theta_data, k0, min(N, k0 + kb), stream)
+                plan.paint(bufs["out"].data_ptr(), stream)
+                t = plan.timings()  # HIP events recorded on the launch stream around each stage
+                kern["prepare_ms"] += t["prepare_ms"]
+                kern["paint_ms"] += t["paint_ms"]
+            kern["pack_ms"] += t["pack_ms"]
+            return s
 
     def fence():
         torch.cuda.synchronize()
@@ -235,17 +278,26 @@ def main():
         dt = float(tt.item())
     for k in kern:
         kern[k] /= max(args.steps, 1)
+    ranges = None
+    if sharded:
+        mine = torch.tensor([shard.range[0], shard.range[1], int(kern["paint_ms"] * 1e3)], dtype=torch.int64, device="cuda")
+        if world > 1:
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        ranges = [[int(v[0]), int(v[1]), int(v[2]) / 1e3] for v in allr]
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
+        chunks = 1 if sharded else world  # chunks painted per step by the whole job
         u_nominal = float(N) * (N - 1) * L
         u_actual = 2.0 * (N - 1) * sum_nd
-        t_paint = kern["paint_ms"] * 1e-3
-        # Algorithmic work of the recursion kernel (per launch = one chunk, all N targets).  FP64 flop per state and
-        # site: 3 forward (add, multiply, accumulate) + 4 backward as the reference writes it (add, fused multiply-
-        # add = 2, accumulate): 7, the figure `frac` is priced with.  With one theta for painter and data the
-        # kernel runs the backward pass on the emission-weighted state, which takes 3: 6 flop are executed, given
-        # beside it as `frac_executed`.
+        # Algorithmic work of the recursion kernel per chunk (all N targets; with the targets sharded, a rank's
+        # launch does its share of it).  FP64 flop per state and site: 3 forward (add, multiply, accumulate) + 4
+        # backward as the reference writes it (add, fused multiply-add = 2, accumulate): 7, the figure `frac` is
+        # priced with.  With one theta for painter and data the kernel runs the backward pass on the emission-
+        # weighted state, which takes 3: 6 flop are executed, given beside it as `frac_executed`.
         f_alg = 7.0 * (N - 1) * sum_nd
         f_exec = (6.0 if theta_data == theta else 7.0) * (N - 1) * sum_nd
         b_alg = (2.0 * ((N + 7) // 8) * sum_nd              # one packed haplotype row per site and pass
@@ -254,24 +306,35 @@ def main():
                  + ((N + 7) // 8) * L + 8.0 * L)            # inputs read once
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and not sharded:
             try:
                 tj = json.load(open(tp))
                 traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         geo = plan.geometry()
+        if sharded:
+            # the slowest rank's recursion launch sets the pace; its share of the chunk's work is what it painted
+            t_paint = max(v[2] for v in ranges) * 1e-3
+            share = 1.0 / world
+            parallelism = (f"one chunk, targets sharded over {world} rank(s) in contiguous ranges of equal numbers of "
+                           "derived sites; one broadcast of the packed matrix and one of r per step over RCCL, no reduction")
+        else:
+            t_paint = kern["paint_ms"] * 1e-3
+            share = 1.0
+            parallelism = f"{world} independent chunk(s), one per GPU"
         out = {
             "metric": "HMM cell-updates/sec (N^2*L) for Paint",
-            "value": u_nominal * world / dt * args.steps,
+            "value": u_nominal * chunks / dt * args.steps,
             "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "N": N, "L": L, "windows": W, "theta": theta, **({"theta_data": theta_data} if theta_data != theta else {}),
-                       "sum_derived_sites": int(sum_nd), "chunks": world, "target_batches": (N + kb - 1) // kb,
-                       "kernel_geometry": geo, "parallelism": f"{world} independent chunk(s), one per GPU"},
-            "actual_state_updates_per_s": u_actual * world / dt * args.steps,
+                       "sum_derived_sites": int(sum_nd), "chunks": chunks,
+                       **({"target_ranges": ranges} if sharded else {"target_batches": (N + kb - 1) // kb}),
+                       "kernel_geometry": geo, "parallelism": parallelism},
+            "actual_state_updates_per_s": u_actual * chunks / dt * args.steps,
             "stage_ms": kern,
             # Compute-bound on the FP64 vector pipe (no MFMA is used: the recurrence is not a contraction).  The
             # benchmark contract knows two roofs, "hbm" and "mfma"; the compute one is reported under the latter
@@ -279,18 +342,23 @@ def main():
             "roofline": {"bound": "mfma", "bound_detail": "valu_fp64",
                          "pipe": "fp64 vector (v_add/v_mul/v_fma_f64); FMA = 2 flop; no matrix instructions",
                          "kernel": "paint_kernel_r (forward / backward recursion, one workgroup per pass)",
-                         "achieved": f_alg / t_paint / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": f_alg / t_paint / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                         "frac_executed": f_exec / t_paint / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
-                         "flop_per_state_update_pair": 7, "kernel_ms": kern["paint_ms"], "traffic": traffic},
-            "roofline_hbm": {"bound": "hbm", "achieved": b_alg / t_paint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": b_alg / t_paint / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b_alg, "traffic": traffic},
+                         "achieved": share * f_alg / t_paint / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": share * f_alg / t_paint / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "frac_executed": share * f_exec / t_paint / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "flop_per_state_update_pair": 7, "kernel_ms": t_paint * 1e3, "traffic": traffic},
+            "roofline_hbm": {"bound": "hbm", "achieved": share * b_alg / t_paint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": share * b_alg / t_paint / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": share * b_alg,
+                             "traffic": traffic},
         }
-        if args.repaint >= 0 and kb >= N:
+        if sharded:
+            out["roofline"]["note"] = ("per GPU: the slowest rank's prepare + recursion time against its 1/n_gpus share of "
+                                       "the chunk's work (the ranges hold equal numbers of derived sites)")
+            kb = 0
+        if args.repaint >= 0 and not sharded and kb >= N:
             out["repaint"] = repaint_leg(plan, torch, bufs["out"], args.repaint, N, R, stream)
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not sharded and not args.no_cpu:
             out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(seq, r, wb, theta)
-        if world == 1 and not args.no_e2e:
+        if world == 1 and not sharded and not args.no_e2e:
             bufs.clear()
             torch.cuda.empty_cache()
             out["end_to_end"] = end_to_end(ra, seq, r, wb, theta, theta_data)

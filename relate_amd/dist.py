@@ -109,11 +109,100 @@ class GpuBackend:
         t.cuda.current_stream(self.device).synchronize()
         return out.cpu().numpy().reshape(self.plan.W, k1 - k0, record_bytes(self.plan.N))
 
+    def timer(self):
+        """Stage times of a step from events on torch's current stream (collectives are ordered on it too)."""
+        torch, dev = self.torch, self.device
+
+        class _Timer:
+            def __init__(self):
+                self.ev = [torch.cuda.Event(enable_timing=True)]
+                self.names = []
+                self.ev[0].record(torch.cuda.current_stream(dev))
+
+            def mark(self, name):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(torch.cuda.current_stream(dev))
+                self.ev.append(e)
+                self.names.append(name)
+
+            def result(self):
+                self.ev[-1].synchronize()
+                return {n: self.ev[i].elapsed_time(self.ev[i + 1]) for i, n in enumerate(self.names)}
+
+        return _Timer()
+
+    def pack_device(self, d_seq, d_r_in, N, L, wb, packed, d_r):
+        """rank 0: pack the byte matrix that already lies in HBM into `packed`; r into the tensor that is broadcast."""
+        if d_r.data_ptr() != d_r_in.data_ptr():
+            d_r.copy_(d_r_in)
+        self.plan.load_device_into(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, packed.data_ptr(), packed.numel(),
+                                   self._stream())
+        self.keep = [packed, d_r]
+
+    def paint_resident(self, theta_p, theta_d, k0, k1, out=None):
+        """Paints [k0,k1) into a device tensor (reused when large enough) and leaves the records there."""
+        t = self.torch
+        st = self._stream()
+        self.plan.prepare(theta_p, theta_d, k0, k1, st)
+        need = self.plan.out_bytes()
+        if out is None or out.numel() < need:
+            out = None
+            out = t.empty(need, dtype=t.uint8, device=self.device)
+        self.plan.paint(out.data_ptr(), st)
+        return out
+
     def paint_to_files(self, theta_p, theta_d, k0, k1, fds):
         """Paints [k0,k1) and writes the records at k*R of the open files `fds` (one per window): batching,
         page-locked copy-back and the writing threads are the library's (relate_plan_paint_to_files)."""
         self.torch.cuda.current_stream(self.device).synchronize()  # the library paints on a stream of its own
         self.plan.paint_to_files(theta_p, theta_d, k0, k1, fds)
+
+
+class ShardedChunk:
+    """One chunk painted by every rank of the default process group with its records left in each rank's HBM:
+    what the multi-GPU benchmark times.  Per step: rank 0 packs the haplotype bytes that lie in its HBM, ONE
+    broadcast of the packed matrix and one of r (the only exchange), every rank works out the same contiguous
+    ranges of equal work from the packed matrix it now holds and paints its own.
+
+    `backend` as in paint_chunk_distributed; `device_seq` / `device_r` are rank 0's device tensors (ignored on the
+    other ranks).  Timings of the last step, milliseconds of this rank: .last = {pack, broadcast, shard, paint}."""
+
+    def __init__(self, backend, N, L, wb, theta_painter, theta_data):
+        import torch.distributed as dist
+        self.dist = dist
+        self.be = backend
+        self.N, self.L, self.wb = N, L, np.ascontiguousarray(wb, dtype=np.int32)
+        self.tp, self.td = float(theta_painter), float(theta_data)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.packed = backend.packed_tensor(N, L)
+        self.d_r = backend.r_tensor(L)
+        self.range = (0, 0)
+        self.out = None
+        self.sum_derived = 0
+        self.last = {}
+
+    def step(self, device_seq=None, device_r=None):
+        be, dist = self.be, self.dist
+        t = be.timer()
+        if self.rank == 0:
+            be.pack_device(device_seq, device_r, self.N, self.L, self.wb, self.packed, self.d_r)
+        t.mark("pack")
+        if self.world > 1:
+            dist.broadcast(self.packed, src=0)
+            dist.broadcast(self.d_r, src=0)
+        t.mark("broadcast")
+        if self.rank != 0:
+            be.adopt(self.N, self.L, self.wb, self.packed, self.d_r)
+        nd = be.derived_counts()
+        bounds = shard_by_work(nd, self.world)
+        k0, k1 = int(bounds[self.rank]), int(bounds[self.rank + 1])
+        self.range = (k0, k1)
+        t.mark("shard")
+        self.sum_derived = int(nd.sum())
+        self.out = be.paint_resident(self.tp, self.td, k0, k1, self.out)
+        t.mark("paint")
+        self.last = t.result()
+        return self.sum_derived
 
 
 def paint_chunk_distributed(output_dir, chunk_index, theta=None, rho=None, backend=None, balance=True):

@@ -52,6 +52,31 @@ class OracleBackend:
         import oracle_lib as ol
         return ol.count_derived(self.seq)
 
+    # what ShardedChunk needs on top of the above
+    def timer(self):
+        import time
+
+        class _T:
+            def __init__(self):
+                self.t = [time.perf_counter()]
+                self.names = []
+
+            def mark(self, name):
+                self.t.append(time.perf_counter())
+                self.names.append(name)
+
+            def result(self):
+                return {n: 1e3 * (self.t[i + 1] - self.t[i]) for i, n in enumerate(self.names)}
+
+        return _T()
+
+    def pack_device(self, d_seq, d_r_in, N, L, wb, packed, d_r):
+        self.pack(d_seq.numpy(), d_r_in.numpy(), wb, packed, d_r)
+
+    def paint_resident(self, theta_p, theta_d, k0, k1, out=None):
+        import oracle_lib as ol
+        return torch.from_numpy(ol.oracle().paint_stones(self.seq, self.r, theta_p, theta_d, self.wb, k0, k1))
+
     def paint_to_files(self, theta_p, theta_d, k0, k1, fds):
         import oracle_lib as ol
         R = ol.record_size(self.seq.shape[1])
@@ -147,3 +172,39 @@ def test_shards_of_equal_work(world):
     # more parts than targets: the first ranges take one target each, the rest stay empty-free at the end
     b = shard_by_work(np.array([5, 7, 9], dtype=np.int32), 3)
     assert list(b) == [0, 1, 2, 3]
+
+
+def _resident_worker(rank, world, port, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import synth_np as sy
+        from relate_amd.dist import ShardedChunk
+        seq, r, wb = sy.make_chunk(N=40, L=700, W=3, seed=19, r_mode="flat")
+        be = OracleBackend()
+        sc = ShardedChunk(be, 40, 700, wb, 0.001, 0.001)
+        d_seq = torch.from_numpy(seq) if rank == 0 else None   # only rank 0 holds the inputs
+        d_r = torch.from_numpy(r) if rank == 0 else None
+        for _ in range(2):
+            total = sc.step(d_seq, d_r)
+        np.save(os.path.join(result_dir, f"rec_{rank}.npy"), sc.out.numpy())
+        np.save(os.path.join(result_dir, f"meta_{rank}.npy"), np.array([sc.range[0], sc.range[1], total]))
+        assert set(sc.last) == {"pack", "broadcast", "shard", "paint"}
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_resident_sharded_step_covers_the_chunk(tmp_path):
+    """ShardedChunk (what bench.py --gpus N times): the ranks' resident records, side by side, are the chunk's."""
+    import oracle_lib as ol
+    import synth_np as sy
+    seq, r, wb = sy.make_chunk(N=40, L=700, W=3, seed=19, r_mode="flat")
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_resident_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    meta = [np.load(tmp_path / f"meta_{i}.npy") for i in range(3)]
+    assert meta[0][0] == 0 and meta[2][1] == 40 and meta[0][1] == meta[1][0] and meta[1][1] == meta[2][0]
+    assert all(int(m[2]) == int(ol.count_derived(seq).sum()) for m in meta)
+    got = np.concatenate([np.load(tmp_path / f"rec_{i}.npy") for i in range(3)], axis=1)
+    assert np.array_equal(got, ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb))
