@@ -235,6 +235,51 @@ int relate_write_chunk(const char* output_dir, int chunk_index, int N, int L, co
  * returns the number of windows (>0) or a negative code. */
 int relate_window_boundaries(int N, int L, const uint8_t* seq, double memory_gb, int max_windows, int32_t* wb);
 
+/* ------------------------------------------------------------------------
+ * 6. Phased haplotypes straight into bit rows: the input side of
+ *      void Data::MakeChunks(const std::string& filename_haps, const std::string& filename_sample,
+ *                            const std::string& filename_map, const std::string& filename_dist,
+ *                            const std::string& file_out, bool use_transitions, float min_memory)
+ *    (src/data.cpp:134-528) without its byte-per-allele matrices: every SNP is packed into N bits as it is
+ *    parsed (haps::ReadSNP, src/data.cpp:553-580), and a chunk goes to the device as bit rows (an eighth of
+ *    chunk_<c>.hap).  Chunks, their overlap of 20 000 SNPs and their windows follow the reference's rules
+ *    (src/data.cpp:145-267), r and rpos its map interpolation (:452-491; filename_dist "unspecified": :397-415).
+ *    .haps, .sample and the map may be gzip-compressed (read through `gunzip -c`, as gzip::open does).
+ *    Where the reference asserts or exits (unsorted positions, a line with too few alleles, too small a memory
+ *    allowance) these calls return an error code.
+ * ------------------------------------------------------------------------ */
+typedef struct relate_haps relate_haps;
+int relate_haps_open(const char* haps_path, const char* sample_path, const char* map_path, double memory_gb,
+                     relate_haps** out);
+void relate_haps_close(relate_haps* h);
+int relate_haps_dims(const relate_haps* h, int* N, int* L, int* num_chunks);
+/* First SNP of chunk `chunk` in the data set, its number of SNPs (overlap included) and of windows: the
+ * contents of parameters_c<chunk>.bin, whose boundaries (num_windows + 1 ints, relative to first_snp)
+ * relate_haps_chunk_windows copies out. */
+int relate_haps_chunk_dims(const relate_haps* h, int chunk, int* first_snp, int* L_chunk, int* num_windows);
+int relate_haps_chunk_windows(const relate_haps* h, int chunk, int32_t* wb);
+/* Whole-data-set vectors, any of which may be NULL: bp (L + 1 ints, the last one base past the last SNP),
+ * dist (L), rpos (L + 1 doubles, Morgans), r (L doubles: 2500 * max(rpos[s+1] - rpos[s], 1e-10)). */
+int relate_haps_positions(const relate_haps* h, int32_t* bp, int32_t* dist, double* rpos, double* r);
+/* The bit matrix on the host: row s starts at rows + s * row_stride_words; bit n of a row (word n / 64, bit
+ * n % 64) is set where haplotype n carries the derived allele, and every bit from N on is set.  The pointer
+ * stays valid until relate_haps_close. */
+int relate_haps_rows(const relate_haps* h, const uint64_t** rows, int* row_stride_words);
+/* Words per bit row for N haplotypes (the layout of relate_haps_rows and relate_plan_load_rows_host). */
+int relate_row_stride_words(int N);
+/* Writes what MakeChunks writes into output_dir, from the bit rows: parameters.bin, props.bin and, per chunk,
+ * parameters_c<c>.bin and chunk_<c>.{hap,bp,dist,r,rpos,state} (src/data.cpp:270-368,:380-391,:437-449,:496-526),
+ * for the stages of the reference that read them.  use_transitions as in MakeChunks (0: transitions get state 0). */
+int relate_haps_write_chunks(const relate_haps* h, const char* output_dir, int use_transitions);
+/* Loads chunk `chunk` into a plan as relate_plan_load_host would load chunk_<chunk>.hap and chunk_<chunk>.r:
+ * uploads the bit rows and r * rho (Data::SetPainting, src/data.cpp:124-129), builds the transposed matrix
+ * on the device.  Returns when the upload has finished; relate_plan_prepare / relate_plan_paint follow as usual. */
+int relate_plan_load_haps_chunk(relate_plan* p, const relate_haps* h, int chunk, double rho);
+/* The same from a caller's own bit rows (layout of relate_haps_rows; L * relate_row_stride_words(N) words, host
+ * memory) and recombination distances. */
+int relate_plan_load_rows_host(relate_plan* p, int N, int L, const uint64_t* rows, const double* r, double rho,
+                               int num_windows, const int32_t* window_boundaries);
+
 #ifdef __cplusplus
 }
 #endif

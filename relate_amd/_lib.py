@@ -66,6 +66,17 @@ PROTOTYPES = {
     "relate_synth_chunk": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_int, u8p, f64p]),
     "relate_write_chunk": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, u8p, f64p, C.c_int, i32p]),
     "relate_window_boundaries": (C.c_int, [C.c_int, C.c_int, u8p, C.c_double, C.c_int, i32p]),
+    "relate_haps_open": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.POINTER(vp)]),
+    "relate_haps_close": (None, [vp]),
+    "relate_haps_dims": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "relate_haps_chunk_dims": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "relate_haps_chunk_windows": (C.c_int, [vp, C.c_int, i32p]),
+    "relate_haps_positions": (C.c_int, [vp, i32p, i32p, f64p, f64p]),
+    "relate_haps_rows": (C.c_int, [vp, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.c_int)]),
+    "relate_row_stride_words": (C.c_int, [C.c_int]),
+    "relate_haps_write_chunks": (C.c_int, [vp, C.c_char_p, C.c_int]),
+    "relate_plan_load_haps_chunk": (C.c_int, [vp, vp, C.c_int, C.c_double]),
+    "relate_plan_load_rows_host": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_uint64), f64p, C.c_double, C.c_int, i32p]),
 }
 
 

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "chunk_io.hpp"
+#include "haps_loader.hpp"
 #include "paint_kernels.h"
 
 namespace {
@@ -38,6 +39,12 @@ int fail(int code, const std::string& msg)
   g_err = msg;
   return code;
 }
+
+}  // namespace
+
+int relate::set_last_error(int code, const std::string& msg) { return fail(code, msg); }
+
+namespace {
 
 #define HIP_TRY(expr)                                                                                   \
   do {                                                                                                  \
@@ -368,6 +375,56 @@ int relate_plan_load_host(relate_plan* p, int N, int L, const uint8_t* seq, cons
   HIP_TRY(hipStreamSynchronize(p->own_stream));
   p->seq_own.release();  // the byte matrix is 8x the packed one: drop it once packed
   return RELATE_OK;
+}
+
+int relate_row_stride_words(int N) { return N < 2 ? 0 : relate::row_stride_words(N); }
+
+int relate_plan_load_rows_host(relate_plan* p, int N, int L, const uint64_t* rows, const double* r, double rho, int W,
+                               const int32_t* wb)
+{
+  if (!p || !rows || !r) return fail(RELATE_EINVAL, "null argument");
+  if (N < 2 || L < 2) return fail(RELATE_EINVAL, "need N >= 2 haplotypes and L >= 2 SNPs");
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st = p->own_stream;
+  if (int rc = plan_set_chunk(p, N, L, W, wb, st)) return rc;
+  const size_t rb = rows_bytes(p), cb = cols_bytes(p), used = (size_t)L * p->row_stride * sizeof(uint64_t);
+  if (p->packed_borrowed) {
+    p->packed = DevBuf();
+    p->packed_borrowed = false;
+  }
+  if (int rc = p->packed.reserve(rb + cb)) return rc;
+  if (int rc = p->r_own.reserve(sizeof(double) * (size_t)L)) return rc;
+  uint64_t* d_rows = p->packed.as<uint64_t>();
+  uint64_t* d_cols = reinterpret_cast<uint64_t*>(static_cast<char*>(p->packed.p) + rb);
+  // r times rho (Data::SetPainting, src/data.cpp:124-129), in page-locked staging so that the upload is a plain DMA
+  void* stage = nullptr;
+  if (int rc = stage_block(p, sizeof(double) * (size_t)L, &stage)) return rc;
+  double* hr = static_cast<double*>(stage);
+  for (int s = 0; s < L; s++) hr[s] = r[s] * rho;
+  HIP_TRY(hipEventRecord(p->ev[0], st));
+  HIP_TRY(hipMemcpyAsync(p->r_own.p, hr, sizeof(double) * (size_t)L, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_rows, rows, used, hipMemcpyHostToDevice, st));
+  // slack after the last row is read (never used) by the recursion kernel: keep it defined
+  HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(d_rows) + used, 0, rb - used, st));
+  HIP_TRY(relate::launch_transpose(d_rows, d_cols, N, L, p->row_stride, p->col_stride, st));
+  HIP_TRY(hipEventRecord(p->ev[1], st));
+  HIP_TRY(hipStreamSynchronize(st));  // the caller's rows and the staging block are free again
+  p->have_pack = true;
+  p->d_rows = d_rows;
+  p->d_cols = d_cols;
+  p->d_r = p->r_own.as<double>();
+  return RELATE_OK;
+}
+
+int relate_plan_load_haps_chunk(relate_plan* p, const relate_haps* h, int chunk, double rho)
+{
+  if (!p || !h) return fail(RELATE_EINVAL, "null argument");
+  if (chunk < 0 || chunk >= (int)h->chunks.size()) return fail(RELATE_EINVAL, "no such chunk");
+  const relate::HapsChunk& c = h->chunks[(size_t)chunk];
+  if (h->row_stride != relate::row_stride_words(h->N)) return fail(RELATE_EINVAL, "data set packed with another row width");
+  if ((size_t)(c.first_snp + c.L) * h->row_stride > h->rows.size()) return fail(RELATE_EINVAL, "chunk lies outside the data set");
+  return relate_plan_load_rows_host(p, h->N, c.L, h->rows.data() + (size_t)c.first_snp * h->row_stride,
+                                    h->r.data() + c.first_snp, rho, (int)c.wb.size() - 1, c.wb.data());
 }
 
 int relate_plan_packed(relate_plan* p, void** d_packed, size_t* bytes)

@@ -120,6 +120,18 @@ class Plan:
                                           wb.ctypes.data_as(i32p)))
         self._set(N, L, wb)
 
+    def load_rows_host(self, N, rows, r, wb, rho=1.0):
+        """Bit rows (L x relate_row_stride_words(N) uint64, bits from N on set) and r from host arrays."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        wb = _wb(wb)
+        L = rows.shape[0]
+        if rows.ndim != 2 or rows.shape[1] != lib().relate_row_stride_words(N) or r.shape != (L,):
+            raise ValueError("rows must be (L, relate_row_stride_words(N)) and r (L,)")
+        check(lib().relate_plan_load_rows_host(self._h, N, L, rows.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                               r.ctypes.data_as(f64p), float(rho), len(wb) - 1, wb.ctypes.data_as(i32p)))
+        self._set(N, L, wb)
+
     def packed(self):
         p, n = vp(), C.c_size_t()
         check(lib().relate_plan_packed(self._h, C.byref(p), C.byref(n)))
