@@ -527,8 +527,8 @@ static int regs_words_per_lane(int M, int G)
 }
 
 // Words per packed row: a multiple of 8 that holds the N bits and, beyond 80 words, all G x MPL words that the
-// narrowest kernel geometry reads of a row (it needs the zero padding bits of every word it reads: 88 words
-// of bits take 96, as 4 x 24, 2 x 48 or 8 x 12).
+// narrowest kernel geometry reads of a row (every word it reads must carry the padding that pack_rows writes,
+// set bits, i.e. states that never mismatch: 88 words of bits take 96, as 4 x 24, 2 x 48 or 8 x 12).
 int row_stride_words(int N)
 {
   const int M = (N + 63) / 64;
