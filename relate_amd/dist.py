@@ -199,7 +199,8 @@ class ShardedChunk:
         self.range = (k0, k1)
         t.mark("shard")
         self.sum_derived = int(nd.sum())
-        self.out = be.paint_resident(self.tp, self.td, k0, k1, self.out)
+        if k1 > k0:  # more ranks than targets with work leaves some ranges empty
+            self.out = be.paint_resident(self.tp, self.td, k0, k1, self.out)
         t.mark("paint")
         self.last = t.result()
         return self.sum_derived
