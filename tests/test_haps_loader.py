@@ -253,3 +253,29 @@ def test_malformed_input_is_refused_with_a_message(tmp_path, what):
         Haps(haps, sample, gmap, mem)
     assert str(e.value).split(": ", 1)[1].strip()
     assert e.value.code == {"unsorted": -1, "short_line": -1, "memory": -5, "missing": -2, "one_map_line": -1}[what]
+
+
+def test_command_line_makechunks_writes_the_same_files(tmp_path):
+    """relate-gpu --mode MakeChunks (options of pipeline/MakeChunks.cpp:15-72) against the library call."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(ra.library_path()), "relate-gpu")
+    if not os.path.exists(exe):
+        pytest.skip("relate-gpu has not been built")
+    seq, bp, map_bp, map_cm, (haps, sample, gmap, states), mem = make_case(tmp_path, N=20, L=300, seed=13, budget=20 * 301.0)
+    a, b = tmp_path / "by_cli", tmp_path / "by_call"
+    cmd = [exe, "--mode", "MakeChunks", "--haps", haps, "--sample", sample, "--map", gmap, "-o", str(a), "--memory", repr(mem),
+           "--transversion"]
+    done = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stderr
+    b.mkdir()
+    with Haps(haps, sample, gmap, mem) as h:
+        h.write_chunks(str(b), use_transitions=False)
+    names = sorted(os.listdir(a))
+    assert names == sorted(os.listdir(b)) and "chunk_0.hap" in names and "parameters.bin" in names and "props.bin" in names
+    for n in names:
+        assert (a / n).read_bytes() == (b / n).read_bytes(), n
+    st = np.fromfile(a / "chunk_0.state", dtype=np.int32)
+    assert np.array_equal(st[1:], states)
+    # an existing directory is refused, as the reference refuses it
+    again = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert again.returncode == 1 and "already exists" in again.stderr
