@@ -26,6 +26,8 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+
 #include "chunk_io.hpp"
 #include "haps_loader.hpp"
 #include "paint_kernels.h"
@@ -964,6 +966,24 @@ std::vector<int> plan_batches(const std::vector<int32_t>& nd, int k_begin, size_
   return cuts;
 }
 
+// Host threads that carry slabs from the pinned ring to their destination.  A thread that copies into fresh
+// pageable memory moves about 8 GB/s (it takes the page faults), the link five to six times that: half of
+// the cores this process may run on, between 4 and 12.  RELATE_COPY_THREADS overrides it (measurements).
+int copy_back_threads()
+{
+  static const int n = [] {
+    if (const char* e = std::getenv("RELATE_COPY_THREADS")) {
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 64) return v;
+    }
+    cpu_set_t set;
+    int cores = 8;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cores = CPU_COUNT(&set);
+    return std::max(4, std::min(12, cores / 2));
+  }();
+  return n;
+}
+
 // sink(w, k0, nk, ptr): the records of targets [k0, k0+nk) of window w, contiguous at ptr (host memory).
 // The records come back window by window through a ring of pinned slots, and a few host threads hand each
 // window's slab to the sink as soon as it has arrived: the sink (a memcpy into pageable memory, or pwrite) is
@@ -1012,7 +1032,7 @@ int paint_range(relate_plan* p, double theta_p, double theta_d, int k_begin, int
       return fail(RELATE_EGPU, std::string("hipEventCreate: ") + hipGetErrorString(e));
     }
   }
-  const int n_threads = std::min(4, std::min(W, n_slots));
+  const int n_threads = std::min(copy_back_threads(), std::min(W, n_slots));
   for (size_t b = 0; b + 1 < cuts.size() && rc == RELATE_OK; b++) {
     const int k0 = cuts[b], k1 = cuts[b + 1], nk = k1 - k0;
     rc = relate_plan_prepare(p, theta_p, theta_d, k0, k1, nullptr, p->own_stream);
