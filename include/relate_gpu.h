@@ -190,6 +190,31 @@ int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, i
 int relate_distance_matrix_noalloc(int device, int N, const void* d_topology, int pitch, const void* d_logscales,
                                    int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
                                    const double* weight_left, const double* weight_right, void* d_matrix, void* stream);
+/* DistanceMeasure with the topology of the current section and the matrix in HBM: the object
+ * AncesTreeBuilder::BuildTopology (src/anc_builder.cpp:265-421) asks for the distance matrix of a SNP,
+ *   class DistanceMeasure { ...; void GetTopologyWithRepaint(const int snp); void GetMatrix(const int snp); }
+ * (src/anc_builder.hpp:35-90, src/anc_builder.cpp:53-211).  The reference's bookkeeping (section,
+ * section_startpos, section_endpos, v_snp_prev, v_rpos_prev, v_rpos_next) is kept on the host under its own
+ * names; re-painting and the matrix run on the device through the two plan calls above.
+ * plan: chunk loaded, prepared for all N targets with theta_painter == theta_data, painted; d_stones: what
+ * relate_plan_paint wrote (device pointer); seq: Data::sequence (L x N bytes '0'/'1'), rpos: Data::rpos
+ * (L + 1 doubles), both host, both copied.  first_section: the window the first call re-paints (0 for a
+ * chunk walked from its start).  The plan and d_stones must outlive the object. */
+typedef struct relate_distance relate_distance;
+int relate_distance_new(relate_plan* plan, const uint8_t* seq, const double* rpos, const void* d_stones, int first_section,
+                        relate_distance** out);
+void relate_distance_free(relate_distance* d);
+/* GetTopologyWithRepaint(snp): re-paints the next section for every target and resets the bookkeeping for
+ * `snp`, which must lie inside that section (the reference asserts it, :106-107). */
+int relate_distance_get_topology_with_repaint(relate_distance* d, int snp, void* stream);
+/* What BuildTopology does to the bookkeeping when it moves on to `snp` (src/anc_builder.cpp:331-335). */
+int relate_distance_advance(relate_distance* d, int snp);
+/* GetMatrix(snp): re-paints first if snp lies beyond the current section (:115-118); N x N floats into d_matrix
+ * (device pointer), row minimum subtracted, zero diagonal.  Enqueues on `stream`. */
+int relate_distance_get_matrix(relate_distance* d, int snp, void* d_matrix, void* stream);
+/* The bookkeeping as it stands (any pointer may be NULL; the vectors have N entries). */
+int relate_distance_state(const relate_distance* d, int* section, int* section_startpos, int* section_endpos,
+                          int64_t* v_snp_prev, double* v_rpos_prev, double* v_rpos_next);
 /* nd_k of every haplotype of the loaded chunk (the number of sites its list holds: its derived sites and the
  * two forced ends, src/fast_painting.cpp:60-110), N ints on the host; the cost of painting target k is
  * proportional to it.  Waits for the result. */

@@ -9,4 +9,4 @@ GPU, every compute call raises."""
 from ._lib import RelateError, lib, library_path, record_bytes  # noqa: F401
 from .paint import Data, FastPainting, Plan, paint_chunk, paint_stones  # noqa: F401
 from .synth import synth_chunk, window_boundaries, write_chunk  # noqa: F401
-from .topology import DistanceMeasure  # noqa: F401
+from .topology import DistanceMeasure, NativeDistanceMeasure  # noqa: F401

@@ -56,6 +56,12 @@ PROTOTYPES = {
     "relate_plan_repaint": (C.c_int, [vp, C.c_int, vp, vp, vp, vp]),
     "relate_plan_distance_matrix": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int64, i64p, u8p, f64p, f64p, vp, vp]),
     "relate_distance_matrix_noalloc": (C.c_int, [C.c_int, C.c_int, vp, C.c_int, vp, C.c_int64, i64p, u8p, f64p, f64p, vp, vp]),
+    "relate_distance_new": (C.c_int, [vp, u8p, f64p, vp, C.c_int, C.POINTER(vp)]),
+    "relate_distance_free": (None, [vp]),
+    "relate_distance_get_topology_with_repaint": (C.c_int, [vp, C.c_int, vp]),
+    "relate_distance_advance": (C.c_int, [vp, C.c_int]),
+    "relate_distance_get_matrix": (C.c_int, [vp, C.c_int, vp, vp]),
+    "relate_distance_state": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), i64p, f64p, f64p]),
     "relate_plan_derived_counts": (C.c_int, [vp, i32p]),
     "relate_shard_by_work": (C.c_int, [C.c_int, i32p, C.c_int, i32p]),
     "relate_plan_paint_to_files": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),

@@ -1487,3 +1487,173 @@ int relate_paint_chunk(const char* output_dir, int chunk_index, const double* th
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// DistanceMeasure (src/anc_builder.hpp:35-90, src/anc_builder.cpp:9-211) with the topology of the current
+// section and the matrix in HBM: the object AncesTreeBuilder::BuildTopology asks for the distance matrix of
+// a SNP.  What stays on the host is the reference's own bookkeeping, under its own names.
+struct relate_distance {
+  relate_plan* plan = nullptr;
+  const uint8_t* d_stones = nullptr;
+  int N = 0, L = 0;
+  int words = 0;                  // 64-bit words per SNP of `derived`
+  std::vector<uint64_t> derived;  // bit n of row s: haplotype n carries the derived allele at SNP s
+  std::vector<double> rpos;       // Data::rpos, L + 1
+  int section = 0, section_startpos = -1, section_endpos = -1;
+  std::vector<int64_t> v_snp_prev;
+  std::vector<double> v_rpos_prev, v_rpos_next;
+  DevBuf topology, logscales;
+  int64_t rows = 0;
+  int pitch = 0;
+  std::vector<int64_t> row_offsets, row_index;
+  std::vector<uint8_t> interpolate;
+  std::vector<double> weight_left, weight_right;
+  bool is_derived(int s, int n) const { return (derived[(size_t)s * words + (n >> 6)] >> (n & 63)) & 1ull; }
+};
+
+extern "C" {
+
+int relate_distance_new(relate_plan* plan, const uint8_t* seq, const double* rpos, const void* d_stones, int first_section,
+                        relate_distance** out)
+{
+  if (!plan || !seq || !rpos || !d_stones || !out) return fail(RELATE_EINVAL, "null argument");
+  *out = nullptr;
+  if (!plan->d_rows) return fail(RELATE_EINVAL, "no chunk loaded");
+  if (plan->K != plan->N || plan->k_begin != 0) return fail(RELATE_EINVAL, "the plan must be prepared for all N targets");
+  if (first_section < 0 || first_section >= plan->W) return fail(RELATE_EINVAL, "no such section");
+  std::unique_ptr<relate_distance> d(new relate_distance());
+  d->plan = plan;
+  d->d_stones = static_cast<const uint8_t*>(d_stones);
+  d->N = plan->N;
+  d->L = plan->L;
+  d->words = (d->N + 63) / 64;
+  d->section = first_section;
+  try {
+    d->derived.assign((size_t)d->L * d->words, 0);
+    for (int s = 0; s < d->L; s++) {
+      const uint8_t* row = seq + (size_t)s * d->N;
+      uint64_t* o = d->derived.data() + (size_t)s * d->words;
+      for (int n = 0; n < d->N; n++)
+        if (row[n] == '1') o[n >> 6] |= 1ull << (n & 63);
+    }
+    d->rpos.assign(rpos, rpos + d->L + 1);
+    d->v_snp_prev.assign((size_t)d->N, 0);
+    d->v_rpos_prev.assign((size_t)d->N, 0.0);
+    d->v_rpos_next.assign((size_t)d->N, 0.0);
+    d->row_offsets.assign((size_t)d->N + 1, 0);
+    d->row_index.assign((size_t)d->N, 0);
+    d->interpolate.assign((size_t)d->N, 0);
+    d->weight_left.assign((size_t)d->N, 0.0);
+    d->weight_right.assign((size_t)d->N, 0.0);
+  } catch (const std::bad_alloc&) {
+    return fail(RELATE_ENOMEM, "out of host memory");
+  }
+  *out = d.release();
+  return RELATE_OK;
+}
+
+void relate_distance_free(relate_distance* d)
+{
+  if (!d) return;
+  (void)hipSetDevice(d->plan->device);
+  d->topology.release();
+  d->logscales.release();
+  delete d;
+}
+
+int relate_distance_get_topology_with_repaint(relate_distance* d, int snp, void* stream)
+{
+  if (!d) return fail(RELATE_EINVAL, "null argument");
+  relate_plan* p = d->plan;
+  if (d->section >= p->W) return fail(RELATE_EINVAL, "no section left in this chunk");
+  if (snp < 0 || snp >= d->L) return fail(RELATE_EINVAL, "SNP outside the chunk");
+  // the interval of the section as its records carry it (src/anc_builder.cpp:66-67, src/fast_painting.cpp:603-606)
+  const int start = p->wb[(size_t)d->section], end = p->wb[(size_t)d->section + 1] - 1;
+  if (snp < start || snp > end) return fail(RELATE_EINVAL, "SNP outside the next section (the reference asserts, :106-107)");
+  HIP_TRY(hipSetDevice(p->device));
+  int64_t rows = 0;
+  int pitch = 0;
+  if (int rc = relate_plan_repaint_layout(p, d->section, &rows, &pitch, d->row_offsets.data())) return rc;
+  if (int rc = d->topology.reserve(sizeof(float) * (size_t)rows * (size_t)pitch)) return rc;
+  if (int rc = d->logscales.reserve(sizeof(float) * (size_t)rows)) return rc;
+  const size_t R = relate_record_bytes(d->N);
+  if (int rc = relate_plan_repaint(p, d->section, d->d_stones + (size_t)d->section * d->N * R, d->topology.p, d->logscales.p, stream))
+    return rc;
+  d->rows = rows;
+  d->pitch = pitch;
+  d->section_startpos = start;
+  d->section_endpos = end;
+  // which row of its topology every haplotype stands at (:85-97) and where its last derived SNP lies (:100-105)
+  std::fill(d->v_snp_prev.begin(), d->v_snp_prev.end(), 0);
+  if (snp > 0)
+    for (int t = snp; t >= start; t--)
+      for (int n = 0; n < d->N; n++)
+        if (d->is_derived(t, n)) d->v_snp_prev[(size_t)n]++;
+  for (int n = 0; n < d->N; n++) {
+    int t = snp;
+    while (!d->is_derived(t, n) && t > 0) t--;
+    d->v_rpos_prev[(size_t)n] = d->rpos[(size_t)t];
+    d->v_rpos_next[(size_t)n] = d->v_rpos_prev[(size_t)n];
+  }
+  d->section++;
+  return RELATE_OK;
+}
+
+int relate_distance_advance(relate_distance* d, int snp)
+{
+  if (!d || snp < 0 || snp >= d->L) return fail(RELATE_EINVAL, "bad argument");
+  for (int n = 0; n < d->N; n++)
+    if (d->is_derived(snp, n)) {
+      d->v_snp_prev[(size_t)n]++;
+      d->v_rpos_prev[(size_t)n] = d->rpos[(size_t)snp];
+    }
+  return RELATE_OK;
+}
+
+int relate_distance_get_matrix(relate_distance* d, int snp, void* d_matrix, void* stream)
+{
+  if (!d || !d_matrix) return fail(RELATE_EINVAL, "null argument");
+  if (snp < 0 || snp >= d->L) return fail(RELATE_EINVAL, "SNP outside the chunk");
+  if (snp > d->section_endpos)
+    if (int rc = relate_distance_get_topology_with_repaint(d, snp, stream)) return rc;
+  const int N = d->N, L = d->L;
+  for (int n = 0; n < N; n++) {
+    const bool direct = d->is_derived(snp, n) || snp == 0 || snp == L - 1;
+    d->interpolate[(size_t)n] = direct ? 0 : 1;
+    d->row_index[(size_t)n] = d->row_offsets[(size_t)n] + d->v_snp_prev[(size_t)n];
+    d->weight_left[(size_t)n] = d->weight_right[(size_t)n] = 0.0;
+    if (direct) continue;
+    if (d->v_rpos_next[(size_t)n] <= d->v_rpos_prev[(size_t)n]) {  // :144-151
+      for (int l = snp; l < L; l++)
+        if (d->is_derived(l, n) || l == L - 1) {
+          d->v_rpos_next[(size_t)n] = d->rpos[(size_t)l];
+          break;
+        }
+    }
+    const double rp = d->v_rpos_prev[(size_t)n], rn = d->v_rpos_next[(size_t)n];
+    if (rp == rn) {
+      d->weight_left[(size_t)n] = d->weight_right[(size_t)n] = 0.5;
+    } else {
+      const double denom = rn - rp;
+      d->weight_left[(size_t)n] = (rn - d->rpos[(size_t)snp]) / denom;
+      d->weight_right[(size_t)n] = (d->rpos[(size_t)snp] - rp) / denom;
+    }
+  }
+  return relate_plan_distance_matrix(d->plan, N, d->topology.p, d->pitch, d->logscales.p, d->rows, d->row_index.data(),
+                                     d->interpolate.data(), d->weight_left.data(), d->weight_right.data(), d_matrix, stream);
+}
+
+int relate_distance_state(const relate_distance* d, int* section, int* section_startpos, int* section_endpos,
+                          int64_t* v_snp_prev, double* v_rpos_prev, double* v_rpos_next)
+{
+  if (!d) return fail(RELATE_EINVAL, "null argument");
+  if (section) *section = d->section;
+  if (section_startpos) *section_startpos = d->section_startpos;
+  if (section_endpos) *section_endpos = d->section_endpos;
+  if (v_snp_prev) std::copy(d->v_snp_prev.begin(), d->v_snp_prev.end(), v_snp_prev);
+  if (v_rpos_prev) std::copy(d->v_rpos_prev.begin(), d->v_rpos_prev.end(), v_rpos_prev);
+  if (v_rpos_next) std::copy(d->v_rpos_next.begin(), d->v_rpos_next.end(), v_rpos_next);
+  return RELATE_OK;
+}
+
+}  // extern "C"

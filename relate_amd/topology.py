@@ -13,9 +13,11 @@ the host is the reference's own bookkeeping, under its own names: v_snp_prev, v_
 The painter behind the re-painting is the one the plan was prepared with; the reference builds it from Data
 (FastPainting painter(*data), src/anc_builder.cpp:59), i.e. prepare the plan with theta_painter == theta_data.
 """
+import ctypes as C
+
 import numpy as np
 
-from ._lib import record_bytes
+from ._lib import check, f64p, i64p, lib, record_bytes, u8p, vp
 
 
 class DistanceMeasure:
@@ -99,3 +101,48 @@ class DistanceMeasure:
                                   self.matrix.data_ptr())
         self._last_args = (self.row_offsets[:N] + self.v_snp_prev, (~direct).astype(np.uint8), wl, wr)
         return self.matrix
+
+
+class NativeDistanceMeasure:
+    """The same object kept by the library (relate_distance_*, include/relate_gpu.h): what a C++ maintainer links
+    against.  Same method names; the matrix is written into a torch tensor of the caller's device."""
+
+    def __init__(self, plan, seq, rpos, stones, section=0):
+        import torch
+        self._torch = torch
+        self.plan, self.stones = plan, stones  # kept alive: the library borrows both
+        self.N, self.L = plan.N, plan.L
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        rpos = np.ascontiguousarray(rpos, dtype=np.float64)
+        if seq.shape != (self.L, self.N) or rpos.shape != (self.L + 1,):
+            raise ValueError("seq must be (L, N) and rpos (L + 1,)")
+        self._h = vp()
+        check(lib().relate_distance_new(plan._h, seq.ctypes.data_as(u8p), rpos.ctypes.data_as(f64p), vp(stones.data_ptr()),
+                                        int(section), C.byref(self._h)))
+        self.matrix = torch.zeros((self.N, self.N), dtype=torch.float32, device=stones.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().relate_distance_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def GetTopologyWithRepaint(self, snp, stream=0):
+        check(lib().relate_distance_get_topology_with_repaint(self._h, int(snp), vp(stream)))
+
+    def advance(self, snp):
+        check(lib().relate_distance_advance(self._h, int(snp)))
+
+    def GetMatrix(self, snp, stream=0):
+        check(lib().relate_distance_get_matrix(self._h, int(snp), vp(self.matrix.data_ptr()), vp(stream)))
+        return self.matrix
+
+    def state(self):
+        sec, lo, hi = C.c_int(), C.c_int(), C.c_int()
+        v = np.zeros(self.N, dtype=np.int64)
+        rp, rn = np.zeros(self.N), np.zeros(self.N)
+        check(lib().relate_distance_state(self._h, C.byref(sec), C.byref(lo), C.byref(hi), v.ctypes.data_as(i64p),
+                                          rp.ctypes.data_as(f64p), rn.ctypes.data_as(f64p)))
+        return {"section": sec.value, "section_startpos": lo.value, "section_endpos": hi.value, "v_snp_prev": v,
+                "v_rpos_prev": rp, "v_rpos_next": rn}

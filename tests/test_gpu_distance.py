@@ -129,3 +129,50 @@ def test_distance_measure_mirror_walks_a_chunk():
                 checked += 1
     assert checked == 4 * W
     plan.close()
+
+
+def test_library_distance_measure_equals_the_python_mirror():
+    """relate_distance_* (the DistanceMeasure a C++ caller links against) walked over a chunk beside
+    relate_amd.DistanceMeasure: the same bookkeeping at every SNP and bit-identical matrices (same kernels, same
+    arguments), across a section change and with an explicit GetTopologyWithRepaint in the middle of a section."""
+    import torch
+    ra = _ra()
+    N, L, W, theta = 75, 300, 3, 0.001
+    seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=71, r_mode="flat")
+    rpos = np.concatenate([[0.0], np.cumsum(r / 2500.0)])
+    plan = ra.Plan(0, 1, 0)
+    plan.load_host(seq, r, wb)
+    plan.prepare(theta, theta, 0, N)
+    stones = torch.zeros(plan.out_bytes(), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    plan.paint(stones.data_ptr())
+    plan.timings()
+    a = ra.DistanceMeasure(plan, seq, rpos, stones)
+    b = ra.NativeDistanceMeasure(plan, seq, rpos, stones)
+    for snp in range(0, L):
+        if snp > 0:
+            a.advance(snp)
+            b.advance(snp)
+        ma = a.GetMatrix(snp).cpu().numpy().copy()
+        torch.cuda.synchronize()
+        mb = b.GetMatrix(snp).cpu().numpy()
+        st = b.state()
+        assert (st["section"], st["section_startpos"], st["section_endpos"]) == (a.section, a.section_startpos, a.section_endpos)
+        assert np.array_equal(st["v_snp_prev"], a.v_snp_prev), f"snp {snp}"
+        assert np.array_equal(st["v_rpos_prev"], a.v_rpos_prev) and np.array_equal(st["v_rpos_next"], a.v_rpos_next)
+        assert np.array_equal(ma.view(np.uint32), mb.view(np.uint32)), f"snp {snp}"
+    assert a.section == W
+    # entering a chunk in the middle of a section (the reference's Assign / GetTopologyWithRepaint with snp > start)
+    mid = (int(wb[1]) + int(wb[2])) // 2
+    c = ra.NativeDistanceMeasure(plan, seq, rpos, stones, section=1)
+    c.GetTopologyWithRepaint(mid)
+    e = ra.DistanceMeasure(plan, seq, rpos, stones, section=1)
+    e.GetTopologyWithRepaint(mid)
+    st = c.state()
+    assert np.array_equal(st["v_snp_prev"], e.v_snp_prev) and np.array_equal(st["v_rpos_prev"], e.v_rpos_prev)
+    assert np.array_equal(c.GetMatrix(mid).cpu().numpy().view(np.uint32), e.GetMatrix(mid).cpu().numpy().view(np.uint32))
+    with pytest.raises(ra.RelateError):  # a SNP outside the next section
+        ra.NativeDistanceMeasure(plan, seq, rpos, stones, section=1).GetTopologyWithRepaint(int(wb[1]) - 1)
+    for o in (b, c):
+        o.close()
+    plan.close()
