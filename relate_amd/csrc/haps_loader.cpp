@@ -224,7 +224,7 @@ int cut_chunks(relate_haps* h, double memory_gb)
     wbnd[0] = snp_begin;
     num_windows = 1;
     while (num_windows + num_over < windows_per_section && chunk_size < max_chunk_size && snp < L) {
-      window_memory += (double)(derived(snp) * (N + 1));
+      window_memory += (double)derived(snp) * (N + 1);  // the reference multiplies two ints: the same value wherever that is defined
       if (window_memory >= budget && in_window > 10) {
         actual_min = std::max(actual_min, window_memory);
         in_window = 0;
