@@ -283,13 +283,28 @@ int parse_haps(relate_haps* h, const std::string& path)
     h->rows.resize(base + (size_t)stride, 0);
     uint64_t* row = h->rows.data() + base;
     int n = 0;
-    for (; p < end && n < N; p++) {
+    while (p < end && n < N) {
+      // four alleles at a time while the text is the usual " 0 1 1 0": eight bytes, spaces at the even ones and
+      // '0' / '1' at the odd ones, whose low bits are the alleles
+      while ((n & 3) == 0 && n + 4 <= N && p + 8 <= end) {
+        uint64_t x;
+        memcpy(&x, p, 8);
+        if ((x & 0xFEFFFEFFFEFFFEFFull) != 0x3020302030203020ull) break;
+        const uint64_t b = (x >> 8) & 0x0001000100010001ull;
+        const uint64_t four = (b | (b >> 15) | (b >> 30) | (b >> 45)) & 0xFull;
+        row[n >> 6] |= four << (n & 63);
+        n += 4;
+        p += 8;
+      }
+      if (p >= end || n >= N) break;
+      // anything else character by character, as haps::ReadSNP does: '0' and '1' count, the rest is skipped
       if (*p == '1') {
         row[n >> 6] |= 1ull << (n & 63);
         n++;
       } else if (*p == '0') {
         n++;
       }
+      p++;
     }
     if (n != N)
       return set_last_error(RELATE_EINVAL, path + ": line " + std::to_string(lineno) + " holds " + std::to_string(n) + " alleles, the sample file announces " + std::to_string(N));

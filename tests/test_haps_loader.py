@@ -279,3 +279,26 @@ def test_command_line_makechunks_writes_the_same_files(tmp_path):
     # an existing directory is refused, as the reference refuses it
     again = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
     assert again.returncode == 1 and "already exists" in again.stderr
+
+
+def test_any_separator_between_alleles(tmp_path):
+    """haps::ReadSNP counts '0' and '1' and skips every other character (src/data.cpp:565-577): tabs, runs of
+    blanks, carriage returns and alleles with nothing between them give the same bit rows as single blanks (the
+    parser's four-at-a-time path takes only the usual " 0 1" text and must hand over cleanly in the middle of a line)."""
+    rng = np.random.default_rng(21)
+    N, L = 131, 60
+    seq, _ = ra.synth_chunk(N, L, 21)
+    bp = np.arange(L) * 10 + 7
+    haps, sample, gmap, _ = write_data_set(str(tmp_path), seq, bp, rng, [1, 1000], [0.0, 1.0], haploid_every=2)
+    seps = [" ", "  ", "\t", "", " \t ", "x"]
+    with open(haps, "w") as f:
+        for s_ in range(L):
+            parts = [f"1 rs{s_} {bp[s_]} A G"]
+            for n in range(N):
+                # long stretches of the usual text, with something else now and then
+                sep = " " if (n == 0 or rng.random() < 0.9) else seps[rng.integers(0, len(seps))]  # the first allele follows the fifth field
+                parts.append(sep + chr(seq[s_, n]))
+            f.write("".join(parts) + ("\r\n" if s_ % 3 == 0 else "\n"))
+    with Haps(haps, sample, gmap, 5.0) as h:
+        assert (h.N, h.L) == (N, L)
+        assert np.array_equal(h.rows(), expected_rows(seq))
