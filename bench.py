@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the Paint hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5]
 
 A step is one complete Paint of one chunk whose inputs (the '0'/'1' haplotype matrix and r) already lie in
 HBM: bit-packing + transpose, per-target precompute, forward/backward recursion of all N targets, records
@@ -27,10 +27,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+WORKLOAD_MEMORY_GB = {"c4": 40.0}  # --memory of MakeChunks for the window rule (default 5, src/data.cpp:145)
 WORKLOADS = {
     # name: (N, L, description)
     "c2": (2000, 50000, "Paint-only single chunk: 2000 haplotypes x 50k SNPs synthetic"),
     "c3": (5008, 100000, "1000G-scale: 5008 haplotypes, 100k-SNP synthetic chunk"),
+    "c4": (20000, 100000, "20k haplotypes x 100k SNPs (windows by the memory rule with --memory 40), painted in batches of targets"),
     "c5": (10000, 50000, "rare-variant-dense: 10k haplotypes x 50k SNPs, skewed recombination map"),
     "tiny": (256, 4000, "tiny functional check"),
 }
@@ -46,26 +48,30 @@ def _cpu_lib():
     return ol.oracle(), "port"
 
 
-def cpu_baseline(seq, r, wb, theta, budget_s=15.0, all_cores_budget_s=20.0):
+def cpu_baseline(seq, r, wb, theta, budget_s=12.0, all_cores_budget_s=15.0, o3_budget_s=8.0):
     """The reference's own painting code (oracle/_ref, where it was built) or its C restatement (oracle/), timed
     on the host: on one core -- the reference's execution model, a single-threaded loop over the targets
-    (pipeline/Paint.cpp:78-82) -- and on all cores of this process's CPU share with the targets split over
-    threads.  Both on a sample of targets of the same chunk: blocks of consecutive targets spread over the panel."""
+    (pipeline/Paint.cpp:78-82) -- on all cores of this process's CPU share with the targets split over threads,
+    and on one core again with the -O3 / AVX2 build of the same sources.  All on a sample of targets of the same
+    chunk: blocks of consecutive targets spread over the panel; the chunk is handed over once (a handle)."""
     import concurrent.futures as cf
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
     lib, kind = _cpu_lib()
     L, N = seq.shape
+    chunk = lib.open_chunk(seq, r, theta)
     t0 = time.perf_counter()
-    lib.paint_stones(seq, r, theta, theta, wb, 0, 2)
+    first = chunk.paint_stones(theta, wb, 0, 2)
     per_target = (time.perf_counter() - t0) / 2
-    block = 4  # consecutive targets per call (the compiled reference copies the haplotype matrix once per call)
+    block = 4  # consecutive targets per call
     nblocks = int(max(1, min(64, budget_s / max(per_target * block, 1e-6))))
     starts = np.linspace(0, N - block, nblocks).astype(int)
     t0 = time.perf_counter()
     for k in starts:
-        lib.paint_stones(seq, r, theta, theta, wb, int(k), int(k) + block)
+        chunk.paint_stones(theta, wb, int(k), int(k) + block)
     dt = time.perf_counter() - t0
     ks = nblocks * block
-    one = {"value": ks * (N - 1) * L / dt, "unit": "cell-updates/s", "cores": 1, "kind": kind,
+    one = {"value": ks * (N - 1) * L / dt, "unit": "cell-updates/s", "cores": 1, "kind": kind, "build": "-O2",
            "sample": f"{ks} of {N} targets of the same chunk ({nblocks} blocks of {block}), {dt:.1f} s on one core"}
     # all cores: the affinity mask is what this process may use (the machine may have many more)
     try:
@@ -74,19 +80,39 @@ def cpu_baseline(seq, r, wb, theta, budget_s=15.0, all_cores_budget_s=20.0):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores) or cores)))
     per_thread = int(max(1, min(16, all_cores_budget_s / max(dt / nblocks, 1e-6))))
-    starts = np.linspace(0, N - block, cores * per_thread).astype(int)
+    starts_all = np.linspace(0, N - block, cores * per_thread).astype(int)
 
     def work(k):
-        lib.paint_stones(seq, r, theta, theta, wb, int(k), int(k) + block)  # ctypes releases the GIL
+        chunk.paint_stones(theta, wb, int(k), int(k) + block)  # ctypes releases the GIL; the chunk is only read
 
     t0 = time.perf_counter()
     with cf.ThreadPoolExecutor(max_workers=cores) as ex:
-        list(ex.map(work, starts))
+        list(ex.map(work, starts_all))
     dta = time.perf_counter() - t0
-    ka = len(starts) * block
-    allc = {"value": ka * (N - 1) * L / dta, "unit": "cell-updates/s", "cores": cores, "kind": kind,
-            "sample": f"{ka} of {N} targets ({len(starts)} blocks of {block} over {cores} threads), {dta:.1f} s"}
-    return one, allc
+    ka = len(starts_all) * block
+    allc = {"value": ka * (N - 1) * L / dta, "unit": "cell-updates/s", "cores": cores, "kind": kind, "build": "-O2",
+            "sample": f"{ka} of {N} targets ({len(starts_all)} blocks of {block} over {cores} threads), {dta:.1f} s"}
+    chunk.close()
+    # the same sources built -O3 -march=x86-64-v3 -ffp-contract=off (same bytes out, checked on the first targets)
+    o3 = None
+    fast = ol.fast_build(kind)
+    if fast is not None:
+        try:
+            fchunk = fast.open_chunk(seq, r, theta)
+            same = bool(np.array_equal(fchunk.paint_stones(theta, wb, 0, 2), first))
+            nb3 = int(max(1, min(nblocks, o3_budget_s / max(dt / nblocks, 1e-6))))
+            starts3 = np.linspace(0, N - block, nb3).astype(int)
+            t0 = time.perf_counter()
+            for k in starts3:
+                fchunk.paint_stones(theta, wb, int(k), int(k) + block)
+            dt3 = time.perf_counter() - t0
+            fchunk.close()
+            o3 = {"value": nb3 * block * (N - 1) * L / dt3, "unit": "cell-updates/s", "cores": 1, "kind": kind,
+                  "build": "-O3 -march=x86-64-v3 -ffp-contract=off", "same_bytes_as_O2": same,
+                  "sample": f"{nb3 * block} of {N} targets ({nb3} blocks of {block}), {dt3:.1f} s on one core"}
+        except Exception as e:  # an unsupported instruction set on this host, for instance
+            o3 = {"skipped": repr(e)}
+    return one, allc, o3
 
 
 def end_to_end(ra, seq, r, wb, theta, theta_data):
@@ -202,7 +228,7 @@ def main():
     seq = r = wb = None
     if not sharded or rank == 0:
         seq, r = ra.synth_chunk(N, L, seed=2 + (0 if sharded else rank), skewed_map=(args.workload == "c5"))
-        wb = ra.window_boundaries(seq, memory_gb=5.0)
+        wb = ra.window_boundaries(seq, memory_gb=WORKLOAD_MEMORY_GB.get(args.workload, 5.0))
     if sharded and world > 1:
         box = [wb]
         dist.broadcast_object_list(box, src=0)
@@ -336,15 +362,18 @@ def main():
                        "kernel_geometry": geo, "parallelism": parallelism},
             "actual_state_updates_per_s": u_actual * chunks / dt * args.steps,
             "stage_ms": kern,
-            # Compute-bound on the FP64 vector pipe (no MFMA is used: the recurrence is not a contraction).  The
-            # benchmark contract knows two roofs, "hbm" and "mfma"; the compute one is reported under the latter
-            # name with the pipe spelt out: vector FP64 peaks at the same 78.6 TFLOP/s as the FP64 matrix pipe.
-            "roofline": {"bound": "mfma", "bound_detail": "valu_fp64",
+            # Compute-bound on the FP64 vector pipe (no MFMA is used: the recurrence is not a contraction), so the
+            # bound is named for what binds.  Of the two roofs the benchmark contract lists ("hbm", "mfma") the
+            # nearest is the second: vector FP64 peaks at the same 78.6 TFLOP/s as the FP64 matrix pipe.
+            "roofline": {"bound": "valu_fp64", "bound_contract_name": "mfma",
                          "pipe": "fp64 vector (v_add/v_mul/v_fma_f64); FMA = 2 flop; no matrix instructions",
                          "kernel": "paint_kernel_r (forward / backward recursion, one workgroup per pass)",
                          "achieved": share * f_alg / t_paint / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": share * f_alg / t_paint / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                          "frac_executed": share * f_exec / t_paint / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "frac_note": "frac / achieved price the launch at the algorithmic 7 flop per state and site pair "
+                                      "(3 forward + 4 backward as the reference writes them); frac_executed is the hardware "
+                                      "utilisation: flop the kernel really issued (6 with one theta) over the same time",
                          "flop_per_state_update_pair": 7, "kernel_ms": t_paint * 1e3, "traffic": traffic},
             "roofline_hbm": {"bound": "hbm", "achieved": share * b_alg / t_paint / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": share * b_alg / t_paint / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": share * b_alg,
@@ -357,7 +386,9 @@ def main():
         if args.repaint >= 0 and not sharded and kb >= N:
             out["repaint"] = repaint_leg(plan, torch, bufs["out"], args.repaint, N, R, stream)
         if world == 1 and not sharded and not args.no_cpu:
-            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(seq, r, wb, theta)
+            out["cpu_baseline"], out["cpu_baseline_all_cores"], o3 = cpu_baseline(seq, r, wb, theta)
+            if o3 is not None:
+                out["cpu_baseline_o3"] = o3
         if world == 1 and not sharded and not args.no_e2e:
             bufs.clear()
             torch.cuda.empty_cache()

@@ -174,19 +174,26 @@ int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* 
  *                    is the first or last SNP), 1 where it mixes rows row_index[n] and row_index[n]+1,
  *   weight_left[n], weight_right[n] = the two weights of that mix (:152-161; ignored where interpolate[n] == 0).
  * d_matrix receives N x N floats, row n = distances from n (matrix[n][m] of the reference), row minimum
- * subtracted, zero diagonal.  total_rows bounds the row indices. */
+ * subtracted, zero diagonal.  total_rows bounds the row indices.
+ * The two exponentials of a mixed row, exp(logscale_prev - logscale_next) and its inverse (:171-172), are taken
+ * on the host with the C library's exp, as the reference takes them, so that the matrix is the reference's bit
+ * for bit (its consumer compares distances with ==, src/tree_builder.cpp:279-299): the call gathers the 2N
+ * logscales it needs on the device, fetches them -- which waits for `stream` once -- and then enqueues the
+ * kernel.  relate_distance_get_matrix below keeps a host copy of the section's logscales and never waits. */
 int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, int pitch, const void* d_logscales,
                                 int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
                                 const double* weight_left, const double* weight_right, void* d_matrix, void* stream);
-/* relate_plan_distance_matrix for callers that cannot allocate: code under HIP graph capture, loops that ask
- * for one matrix per tree, harnesses that forbid hipMalloc.  It has no counterpart in the reference (whose
- * GetMatrix fills a host matrix in place); same arguments, same kernel and same result as the entry point above,
- * without a plan.  The per-row arguments (25 bytes per row) are staged in a fixed array inside the library's
- * code object, of which every GPU holds its own copy (900 KiB) until the process ends: N may be at most 36 864,
- * larger values are refused with RELATE_ERANGE.  The call allocates nothing on the device or the host; it
- * copies the four host arrays (pageable memory is fine) and launches on `stream`.  All calls on one GPU share
- * that GPU's array: calls that overlap in time on one GPU (different streams, or threads) race; calls on one
- * stream follow each other safely. */
+/* relate_plan_distance_matrix for callers that cannot allocate: loops that ask for one matrix per tree inside a
+ * serving process, harnesses that forbid hipMalloc.  It has no counterpart in the reference (whose GetMatrix
+ * fills a host matrix in place); same arguments, same kernel and same result as the entry point above, without
+ * a plan.  The per-row arguments (41 bytes per row) are staged in a fixed array inside the library's code
+ * object, of which every GPU holds its own copy (1.44 MiB) until the process ends, and in a fixed host array of
+ * the same size: N may be at most 36 864, larger values are refused with RELATE_ERANGE.  The call allocates
+ * nothing on the device or the host; it copies the four host arrays (pageable memory is fine), waits for
+ * `stream` (the logscales come back for the exponentials, and the host array must be free again on return) and
+ * returns once the matrix has been computed.  It is therefore not a call to make under HIP graph capture.
+ * All calls on one GPU share that GPU's array, and all calls of the process the host array: the library holds a
+ * lock for the whole call, so concurrent callers are served one after the other instead of racing. */
 int relate_distance_matrix_noalloc(int device, int N, const void* d_topology, int pitch, const void* d_logscales,
                                    int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
                                    const double* weight_left, const double* weight_right, void* d_matrix, void* stream);

@@ -78,6 +78,50 @@ int ref_paint_stones(int N, int L, const uint8_t* seq, const double* r, double t
   return rc;
 }
 
+// The same with the reference's Data kept between calls (a handle): a caller that paints many small blocks of
+// targets of one chunk, as the benchmark's CPU baseline does, fills the L x N matrix once instead of per call.
+void* ref_data_new(int N, int L, const uint8_t* seq, const double* r, double theta_data)
+{
+  Data* data = new Data();
+  fill_data(*data, N, L, seq, r, theta_data);
+  return data;
+}
+
+void ref_data_free(void* h) { delete static_cast<Data*>(h); }
+
+int ref_data_paint_stones(void* h, double theta_painter, int W, const int32_t* wb, int k_begin, int k_end, uint8_t* out)
+{
+  Data& data = *static_cast<Data*>(h);
+  const int N = data.N;
+  std::vector<int> window_boundaries(wb, wb + W + 1);
+  std::vector<char*> bufs(W, nullptr);
+  std::vector<size_t> sizes(W, 0);
+  std::vector<FILE*> pfiles(W);
+  for (int w = 0; w < W; w++) {
+    pfiles[w] = open_memstream(&bufs[w], &sizes[w]);
+    if (!pfiles[w]) return 1;
+  }
+  for (int k = k_begin; k < k_end; k++) {
+    if (theta_painter == data.theta) {
+      FastPainting painter(data);
+      painter.PaintSteppingStones(data, window_boundaries, pfiles, k);
+    } else {
+      FastPainting painter((size_t)N, theta_painter);
+      painter.PaintSteppingStones(data, window_boundaries, pfiles, k);
+    }
+  }
+  const size_t R = 56 + (size_t)8 * N;
+  const size_t K = (size_t)(k_end - k_begin);
+  int rc = 0;
+  for (int w = 0; w < W; w++) {
+    fclose(pfiles[w]);
+    if (sizes[w] != K * R) rc = 2;
+    else std::memcpy(out + (size_t)w * K * R, bufs[w], K * R);
+    free(bufs[w]);
+  }
+  return rc;
+}
+
 int ref_repaint_section(int N, int L, const uint8_t* seq, const double* r, double theta, int first, int last,
                         const float* alpha_begin, const float* beta_end, float logscale_alpha,
                         float logscale_beta, int k, float* topology, float* logscales)

@@ -90,10 +90,15 @@ hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const
 hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStream_t st);
 hipError_t launch_fast_log(const float* d_in, float* d_out, int n, hipStream_t st);
 // DistanceMeasure::GetMatrix (src/anc_builder.cpp:113-211) on a device-resident topology: row n of `matrix`
-// from topology row `row[n]` (and the next one where interp[n] != 0, with weights wl[n], wr[n]).
+// from topology row `row[n]` (and the next one where interp[n] != 0, with weights wl[n], wr[n] and the two
+// exponentials of the logscale difference, epn[n] = exp(ls[row] - ls[row+1]), enp[n] = exp(ls[row+1] - ls[row]),
+// taken by the host as the reference takes them, :171-172).
 hipError_t launch_distance_matrix(const float* d_top, int pitch, const float* d_ls, const int64_t* d_row,
-                                  const uint8_t* d_interp, const double* d_wl, const double* d_wr, int N,
-                                  float* d_matrix, hipStream_t st);
+                                  const uint8_t* d_interp, const double* d_wl, const double* d_wr, const float* d_epn,
+                                  const float* d_enp, int N, float* d_matrix, hipStream_t st);
+// out[2n] = ls[row[n]], out[2n+1] = ls[row[n] + (interp[n] ? 1 : 0)]: what the host needs for those exponentials
+hipError_t launch_gather_logscales(const float* d_ls, const int64_t* d_row, const uint8_t* d_interp, int N, float* d_out,
+                                   hipStream_t st);
 
 // Re-painting of one window from its stones (register-resident kernels, repaint_regs.hpp).
 struct RepaintLaunch {

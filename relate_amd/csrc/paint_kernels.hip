@@ -45,7 +45,10 @@ __global__ void fast_log_kernel(const float* __restrict__ in, float* __restrict_
 //   then d[n][n] = 0 and the row minimum -- taken over all m, the diagonal's own value included, as
 //   the reference does -- is subtracted from the off-diagonal entries              (:194-196).
 // The arithmetic keeps the reference's types: weights in double, the mix in double, narrowed to float
-// for fast_log, float from there on; scale = -1.0f (src/anc_builder.hpp:46).
+// for fast_log, float from there on; scale = -1.0f (src/anc_builder.hpp:46).  The two exponentials of a
+// mixed row (:171-172) are NOT taken here: the host computes them with the same libm call as the
+// reference (exp on a double, narrowed) and passes them per row, so that every operation of an entry is
+// an individually rounded IEEE operation and the matrix is the reference's bit for bit.
 __device__ __forceinline__ float distance_entry(bool interp, bool prev_le_next, float tp, float tn, double wl, double wr,
                                                 float e_pn, float e_np, float ls_prev, float ls_next)
 {
@@ -59,12 +62,31 @@ __device__ __forceinline__ float distance_entry(bool interp, bool prev_le_next, 
   return __fmul_rn(__fadd_rn(fast_log_dev((float)x), ls_prev), scale);
 }
 
+// The two logscales every row of the matrix needs, gathered for the host (which takes their exponentials):
+// out[2n] = ls[row[n]], out[2n+1] = ls[row[n] + 1] where the row is mixed, else the same value again.
+__global__ void gather_logscales_kernel(const float* __restrict__ ls, const int64_t* __restrict__ row,
+                                        const uint8_t* __restrict__ interp_flag, int N, float* __restrict__ out)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const long long r0 = row[n];
+  out[2 * n] = ls[r0];
+  out[2 * n + 1] = ls[r0 + (interp_flag[n] ? 1 : 0)];
+}
+
+// ITEMS > 0: thread t keeps its entries m = t + 256 i, i < ITEMS (N <= 256 ITEMS), in registers between the
+// minimum and the subtraction, so every topology element is read and every entry evaluated once.
+// ITEMS == 0: any N; the entries are evaluated a second time after the minimum is known (the second read of
+// the topology rows comes from L2).
+template <int ITEMS>
 __global__ void __launch_bounds__(256) distance_matrix_kernel(const float* __restrict__ top, int pitch,
                                                               const float* __restrict__ ls,
                                                               const int64_t* __restrict__ row,
                                                               const uint8_t* __restrict__ interp_flag,
                                                               const double* __restrict__ wl_all,
-                                                              const double* __restrict__ wr_all, int N,
+                                                              const double* __restrict__ wr_all,
+                                                              const float* __restrict__ e_pn_all,
+                                                              const float* __restrict__ e_np_all, int N,
                                                               float* __restrict__ matrix)
 {
   __shared__ float smin[4];
@@ -76,13 +98,39 @@ __global__ void __launch_bounds__(256) distance_matrix_kernel(const float* __res
   const float ls_prev = ls[r0];
   const float ls_next = interp ? ls[r0 + 1] : ls_prev;
   const double wl = interp ? wl_all[n] : 0.0, wr = interp ? wr_all[n] : 0.0;
-  // `exp(float)` written unqualified in the reference (:171-172): the double function, narrowed on assignment
-  const float e_pn = (float)exp((double)__fsub_rn(ls_prev, ls_next)), e_np = (float)exp((double)__fsub_rn(ls_next, ls_prev));
+  const float e_pn = interp ? e_pn_all[n] : 1.0f, e_np = interp ? e_np_all[n] : 1.0f;
   const bool prev_le_next = ls_prev <= ls_next;
   float mn = __builtin_inff();
-  for (int m = threadIdx.x; m < N; m += 256) {
-    const float v = distance_entry(interp, prev_le_next, tp[m], tn[m], wl, wr, e_pn, e_np, ls_prev, ls_next);
-    if (v < mn) mn = v;
+  float v[ITEMS > 0 ? ITEMS : 1];
+  if constexpr (ITEMS > 0) {
+    // loads first (they are independent), then the arithmetic
+    float a[ITEMS], b[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const int m = threadIdx.x + 256 * i;
+      a[i] = m < N ? tp[m] : 1.0f;
+    }
+    if (interp) {
+#pragma unroll
+      for (int i = 0; i < ITEMS; i++) {
+        const int m = threadIdx.x + 256 * i;
+        b[i] = m < N ? tn[m] : 1.0f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ITEMS; i++) b[i] = a[i];
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const int m = threadIdx.x + 256 * i;
+      v[i] = distance_entry(interp, prev_le_next, a[i], b[i], wl, wr, e_pn, e_np, ls_prev, ls_next);
+      if (m < N && v[i] < mn) mn = v[i];
+    }
+  } else {
+    for (int m = threadIdx.x; m < N; m += 256) {
+      const float x = distance_entry(interp, prev_le_next, tp[m], tn[m], wl, wr, e_pn, e_np, ls_prev, ls_next);
+      if (x < mn) mn = x;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -96,9 +144,17 @@ __global__ void __launch_bounds__(256) distance_matrix_kernel(const float* __res
   for (int i = 1; i < 4; i++)
     if (smin[i] < mn) mn = smin[i];
   float* __restrict__ out = matrix + (long long)n * N;
-  for (int m = threadIdx.x; m < N; m += 256) {
-    const float v = distance_entry(interp, prev_le_next, tp[m], tn[m], wl, wr, e_pn, e_np, ls_prev, ls_next);
-    out[m] = (m == n) ? 0.0f : __fsub_rn(v, mn);
+  if constexpr (ITEMS > 0) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+      const int m = threadIdx.x + 256 * i;
+      if (m < N) out[m] = (m == n) ? 0.0f : __fsub_rn(v[i], mn);
+    }
+  } else {
+    for (int m = threadIdx.x; m < N; m += 256) {
+      const float x = distance_entry(interp, prev_le_next, tp[m], tn[m], wl, wr, e_pn, e_np, ls_prev, ls_next);
+      out[m] = (m == n) ? 0.0f : __fsub_rn(x, mn);
+    }
   }
 }
 
@@ -727,12 +783,27 @@ hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const
   return hipGetLastError();
 }
 
-hipError_t launch_distance_matrix(const float* d_top, int pitch, const float* d_ls, const int64_t* d_row,
-                                  const uint8_t* d_interp, const double* d_wl, const double* d_wr, int N,
-                                  float* d_matrix, hipStream_t st)
+hipError_t launch_gather_logscales(const float* d_ls, const int64_t* d_row, const uint8_t* d_interp, int N, float* d_out,
+                                   hipStream_t st)
 {
-  hipLaunchKernelGGL(distance_matrix_kernel, dim3(N), dim3(256), 0, st, d_top, pitch, d_ls, d_row, d_interp, d_wl, d_wr, N,
-                     d_matrix);
+  hipLaunchKernelGGL(gather_logscales_kernel, dim3((N + 255) / 256), dim3(256), 0, st, d_ls, d_row, d_interp, N, d_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_distance_matrix(const float* d_top, int pitch, const float* d_ls, const int64_t* d_row,
+                                  const uint8_t* d_interp, const double* d_wl, const double* d_wr, const float* d_epn,
+                                  const float* d_enp, int N, float* d_matrix, hipStream_t st)
+{
+#define RELATE_DM(I)                                                                                                   \
+  hipLaunchKernelGGL(distance_matrix_kernel<I>, dim3(N), dim3(256), 0, st, d_top, pitch, d_ls, d_row, d_interp, d_wl, \
+                     d_wr, d_epn, d_enp, N, d_matrix)
+  if (N <= 256 * 4) RELATE_DM(4);
+  else if (N <= 256 * 8) RELATE_DM(8);
+  else if (N <= 256 * 12) RELATE_DM(12);
+  else if (N <= 256 * 20) RELATE_DM(20);
+  else if (N <= 256 * 40) RELATE_DM(40);
+  else RELATE_DM(0);
+#undef RELATE_DM
   return hipGetLastError();
 }
 

@@ -686,64 +686,147 @@ int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* 
   return RELATE_OK;
 }
 
-int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, int pitch, const void* d_logscales,
-                                int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
-                                const double* weight_left, const double* weight_right, void* d_matrix, void* stream)
+}  // extern "C"
+
+namespace {
+
+// Per-row arguments of the distance-matrix kernel as one block, laid out the same way on the host and on the
+// device: row indices, the two weights, the two exponentials, the gathered pair of logscales, the flags.
+struct DmBlock {
+  size_t row, wl, wr, epn, enp, pair, flag, bytes;
+  explicit DmBlock(int N)
+      : row(0), wl((size_t)8 * N), wr((size_t)16 * N), epn((size_t)24 * N), enp((size_t)28 * N), pair((size_t)32 * N),
+        flag((size_t)40 * N), bytes((size_t)41 * N)
+  {
+  }
+};
+
+int check_distance_rows(int N, int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
+                        const double* weight_left, const double* weight_right)
+{
+  bool any_mixed = false;
+  for (int n = 0; n < N; n++) {
+    any_mixed = any_mixed || interpolate[n];
+    if (row_index[n] < 0 || row_index[n] + (interpolate[n] ? 1 : 0) >= total_rows)
+      return fail(RELATE_EINVAL, "topology row index out of range");
+  }
+  if (any_mixed && (!weight_left || !weight_right)) return fail(RELATE_EINVAL, "interpolated rows need weights");
+  return RELATE_OK;
+}
+
+// float exp_logscale_prev_next = exp(logscale_prev - logscale_next), and the other way round
+// (src/anc_builder.cpp:171-172): a float difference, the C library's exp on it as a double, narrowed.
+inline void logscale_exponentials(float ls_prev, float ls_next, float* e_pn, float* e_np)
+{
+  const float d_pn = ls_prev - ls_next, d_np = ls_next - ls_prev;
+  *e_pn = (float)std::exp((double)d_pn);
+  *e_np = (float)std::exp((double)d_np);
+}
+
+// Fills the host block h, uploads it into the device block d and launches the kernel on `st`.
+// h_ls: a host copy of the logscales (total_rows floats), or NULL: then the 2N values needed are gathered on
+// the device and fetched, which waits for `st` once.  h must stay untouched until the upload has left it
+// (`uploaded`, if given, is recorded behind the last upload; without it the function waits itself).
+int distance_matrix_run(int N, const float* d_top, int pitch, const float* d_ls, const float* h_ls,
+                        const int64_t* row_index, const uint8_t* interpolate, const double* weight_left,
+                        const double* weight_right, uint8_t* h, uint8_t* d, float* d_matrix, hipStream_t st,
+                        hipEvent_t uploaded)
+{
+  const DmBlock b(N);
+  int64_t* h_row = reinterpret_cast<int64_t*>(h + b.row);
+  double* h_wl = reinterpret_cast<double*>(h + b.wl);
+  double* h_wr = reinterpret_cast<double*>(h + b.wr);
+  float* h_epn = reinterpret_cast<float*>(h + b.epn);
+  float* h_enp = reinterpret_cast<float*>(h + b.enp);
+  float* h_pair = reinterpret_cast<float*>(h + b.pair);
+  uint8_t* h_flag = h + b.flag;
+  for (int n = 0; n < N; n++) {
+    h_row[n] = row_index[n];
+    h_wl[n] = interpolate[n] ? weight_left[n] : 0.0;
+    h_wr[n] = interpolate[n] ? weight_right[n] : 0.0;
+    h_flag[n] = interpolate[n] ? 1 : 0;
+  }
+  if (h_ls) {
+    for (int n = 0; n < N; n++) {
+      h_pair[2 * n] = h_ls[row_index[n]];
+      h_pair[2 * n + 1] = h_ls[row_index[n] + (interpolate[n] ? 1 : 0)];
+    }
+  } else {
+    HIP_TRY(hipMemcpyAsync(d + b.row, h + b.row, (size_t)8 * N, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + b.flag, h + b.flag, (size_t)N, hipMemcpyHostToDevice, st));
+    HIP_TRY(relate::launch_gather_logscales(d_ls, reinterpret_cast<const int64_t*>(d + b.row), d + b.flag, N,
+                                            reinterpret_cast<float*>(d + b.pair), st));
+    HIP_TRY(hipMemcpyAsync(h + b.pair, d + b.pair, (size_t)8 * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  for (int n = 0; n < N; n++) {
+    if (interpolate[n]) logscale_exponentials(h_pair[2 * n], h_pair[2 * n + 1], &h_epn[n], &h_enp[n]);
+    else h_epn[n] = h_enp[n] = 1.0f;
+  }
+  if (h_ls) HIP_TRY(hipMemcpyAsync(d, h, b.bytes, hipMemcpyHostToDevice, st));
+  else HIP_TRY(hipMemcpyAsync(d + b.wl, h + b.wl, b.pair - b.wl, hipMemcpyHostToDevice, st));
+  if (uploaded) HIP_TRY(hipEventRecord(uploaded, st));
+  HIP_TRY(relate::launch_distance_matrix(d_top, pitch, d_ls, reinterpret_cast<const int64_t*>(d + b.row), d + b.flag,
+                                         reinterpret_cast<const double*>(d + b.wl), reinterpret_cast<const double*>(d + b.wr),
+                                         reinterpret_cast<const float*>(d + b.epn), reinterpret_cast<const float*>(d + b.enp),
+                                         N, d_matrix, st));
+  if (!uploaded) HIP_TRY(hipStreamSynchronize(st));
+  return RELATE_OK;
+}
+
+// relate_plan_distance_matrix with an optional host copy of the logscales (the library's DistanceMeasure keeps one)
+int plan_distance_matrix(relate_plan* p, int N, const void* d_topology, int pitch, const void* d_logscales,
+                         const float* h_logscales, int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
+                         const double* weight_left, const double* weight_right, void* d_matrix, void* stream)
 {
   if (!p || !d_topology || !d_logscales || !row_index || !interpolate || !d_matrix)
     return fail(RELATE_EINVAL, "null argument");
   if (N < 1 || pitch < N) return fail(RELATE_EINVAL, "bad matrix size or pitch");
-  for (int n = 0; n < N; n++) {
-    if (interpolate[n] && (!weight_left || !weight_right)) return fail(RELATE_EINVAL, "interpolated rows need weights");
-    if (row_index[n] < 0 || row_index[n] + (interpolate[n] ? 1 : 0) >= total_rows)
-      return fail(RELATE_EINVAL, "topology row index out of range");
-  }
+  if (int rc = check_distance_rows(N, total_rows, row_index, interpolate, weight_left, weight_right)) return rc;
   HIP_TRY(hipSetDevice(p->device));
   hipStream_t st = p->pick(stream);
-  // one staging block: row indices, weights, flags
-  const size_t nb = (size_t)N * (8 + 8 + 8) + (size_t)N;
+  const DmBlock b(N);
   void* blk = nullptr;
-  if (int rc = stage_block(p, nb, &blk)) return rc;
-  uint8_t* h = static_cast<uint8_t*>(blk);
-  int64_t* hr = reinterpret_cast<int64_t*>(h);
-  double* hl = reinterpret_cast<double*>(h + (size_t)8 * N);
-  double* hw = reinterpret_cast<double*>(h + (size_t)16 * N);
-  uint8_t* hf = h + (size_t)24 * N;
-  for (int n = 0; n < N; n++) {
-    hr[n] = row_index[n];
-    hl[n] = interpolate[n] ? weight_left[n] : 0.0;
-    hw[n] = interpolate[n] ? weight_right[n] : 0.0;
-    hf[n] = interpolate[n] ? 1 : 0;
-  }
-  if (int rc = p->dm_args.reserve(nb)) return rc;
-  HIP_TRY(hipMemcpyAsync(p->dm_args.p, h, nb, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipEventRecord(p->staged, st));
-  p->stage_in_flight = true;
-  uint8_t* d = static_cast<uint8_t*>(p->dm_args.p);
+  if (int rc = stage_block(p, b.bytes, &blk)) return rc;
+  if (int rc = p->dm_args.reserve(b.bytes)) return rc;
   HIP_TRY(hipEventRecord(p->ev[4], st));
-  HIP_TRY(relate::launch_distance_matrix(static_cast<const float*>(d_topology), pitch,
-                                         static_cast<const float*>(d_logscales), reinterpret_cast<const int64_t*>(d),
-                                         d + (size_t)24 * N, reinterpret_cast<const double*>(d + (size_t)8 * N),
-                                         reinterpret_cast<const double*>(d + (size_t)16 * N), N,
-                                         static_cast<float*>(d_matrix), st));
+  p->stage_in_flight = true;  // from here on the block may be feeding an upload
+  if (int rc = distance_matrix_run(N, static_cast<const float*>(d_topology), pitch, static_cast<const float*>(d_logscales),
+                                   h_logscales, row_index, interpolate, weight_left, weight_right, static_cast<uint8_t*>(blk),
+                                   p->dm_args.as<uint8_t>(), static_cast<float*>(d_matrix), st, p->staged))
+    return rc;
   HIP_TRY(hipEventRecord(p->ev[5], st));
   p->have_paint = true;
   return RELATE_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int relate_plan_distance_matrix(relate_plan* p, int N, const void* d_topology, int pitch, const void* d_logscales,
+                                int64_t total_rows, const int64_t* row_index, const uint8_t* interpolate,
+                                const double* weight_left, const double* weight_right, void* d_matrix, void* stream)
+{
+  return plan_distance_matrix(p, N, d_topology, pitch, d_logscales, nullptr, total_rows, row_index, interpolate, weight_left,
+                              weight_right, d_matrix, stream);
+}
+
 // --------------------------------------------------------------------------
-// The distance matrix for callers that cannot allocate (code under HIP graph capture, tight loops that ask
-// for a matrix per tree, harnesses that forbid hipMalloc).  relate_plan_distance_matrix stages its per-row
-// arguments in a device buffer and a page-locked host block that it allocates and grows; here they go into a
-// fixed array in the code object, one copy per GPU, of which the host keeps the address per device.
+// The distance matrix for callers that cannot allocate (tight loops that ask for a matrix per tree, harnesses
+// that forbid hipMalloc).  relate_plan_distance_matrix stages its per-row arguments in a device buffer and a
+// page-locked host block that it allocates and grows; here they go into a fixed array in the code object, one
+// copy per GPU, of which the host keeps the address per device, and a fixed host array of the same size.
 // --------------------------------------------------------------------------
 }  // extern "C"
 
 namespace {
 
 constexpr int kNoAllocMaxN = 36864;  // the widest panel the painting kernels take (8 waves x 72 words)
-constexpr size_t kNoAllocBytes = ((size_t)kNoAllocMaxN * 25 + 255) / 256 * 256;  // row index, two weights, flag per row
+constexpr size_t kNoAllocBytes = ((size_t)kNoAllocMaxN * 41 + 255) / 256 * 256;  // one DmBlock of the widest panel
 static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+alignas(64) unsigned char g_noalloc_host[kNoAllocBytes];  // host side of the same block; one call at a time (mutex)
+std::mutex g_noalloc_host_mutex;
 constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 void* g_scratch_ptr[kMaxDevices] = {};
@@ -779,31 +862,16 @@ int relate_distance_matrix_noalloc(int device, int N, const void* d_topology, in
   const int ndev = relate_device_count();
   if (ndev <= 0) return fail(RELATE_EGPU, "no HIP device visible");
   if (device < 0 || device >= ndev || device >= kMaxDevices) return fail(RELATE_EINVAL, "device index out of range");
-  bool any_mixed = false;
-  for (int n = 0; n < N; n++) {
-    any_mixed = any_mixed || interpolate[n];
-    if (row_index[n] < 0 || row_index[n] + (interpolate[n] ? 1 : 0) >= total_rows)
-      return fail(RELATE_EINVAL, "topology row index out of range");
-  }
-  if (any_mixed && (!weight_left || !weight_right)) return fail(RELATE_EINVAL, "interpolated rows need weights");
+  if (int rc = check_distance_rows(N, total_rows, row_index, interpolate, weight_left, weight_right)) return rc;
   HIP_TRY(hipSetDevice(device));
   unsigned char* d = nullptr;
   if (int rc = scratch_address(device, &d)) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  // four sections of this device's array: row indices, left weights, right weights, flags (the kernel reads a
-  // weight only where the flag is set, so the caller's arrays go in as they are)
-  const size_t n8 = sizeof(int64_t) * (size_t)N;
-  HIP_TRY(hipMemcpyAsync(d, row_index, n8, hipMemcpyHostToDevice, st));
-  if (any_mixed) {
-    HIP_TRY(hipMemcpyAsync(d + n8, weight_left, n8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d + 2 * n8, weight_right, n8, hipMemcpyHostToDevice, st));
-  }
-  HIP_TRY(hipMemcpyAsync(d + 3 * n8, interpolate, (size_t)N, hipMemcpyHostToDevice, st));
-  HIP_TRY(relate::launch_distance_matrix(static_cast<const float*>(d_topology), pitch, static_cast<const float*>(d_logscales),
-                                         reinterpret_cast<const int64_t*>(d), d + 3 * n8,
-                                         reinterpret_cast<const double*>(d + n8), reinterpret_cast<const double*>(d + 2 * n8), N,
-                                         static_cast<float*>(d_matrix), st));
-  return RELATE_OK;
+  // the host block is shared by every call in the process: held until the uploads have left it (the call
+  // returns after the stream has taken them, see distance_matrix_run without an event)
+  std::lock_guard<std::mutex> lk(g_noalloc_host_mutex);
+  return distance_matrix_run(N, static_cast<const float*>(d_topology), pitch, static_cast<const float*>(d_logscales), nullptr,
+                             row_index, interpolate, weight_left, weight_right, g_noalloc_host, d,
+                             static_cast<float*>(d_matrix), static_cast<hipStream_t>(stream), nullptr);
 }
 
 int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float* ms_paint)
@@ -1503,6 +1571,11 @@ struct relate_distance {
   std::vector<int64_t> v_snp_prev;
   std::vector<double> v_rpos_prev, v_rpos_next;
   DevBuf topology, logscales;
+  // host copy of the section's logscales (the exponentials of GetMatrix, :171-172, are taken on the host with
+  // the C library the reference uses); fetched once per re-painting, `ls_fetched` is recorded behind the copy
+  HostBuf h_logscales;
+  hipEvent_t ls_fetched = nullptr;
+  bool ls_pending = false;
   int64_t rows = 0;
   int pitch = 0;
   std::vector<int64_t> row_offsets, row_index;
@@ -1548,6 +1621,8 @@ int relate_distance_new(relate_plan* plan, const uint8_t* seq, const double* rpo
   } catch (const std::bad_alloc&) {
     return fail(RELATE_ENOMEM, "out of host memory");
   }
+  HIP_TRY(hipSetDevice(plan->device));
+  HIP_TRY(hipEventCreateWithFlags(&d->ls_fetched, hipEventDisableTiming));
   *out = d.release();
   return RELATE_OK;
 }
@@ -1556,8 +1631,11 @@ void relate_distance_free(relate_distance* d)
 {
   if (!d) return;
   (void)hipSetDevice(d->plan->device);
+  if (d->ls_pending) (void)hipEventSynchronize(d->ls_fetched);
   d->topology.release();
   d->logscales.release();
+  d->h_logscales.release();
+  if (d->ls_fetched) (void)hipEventDestroy(d->ls_fetched);
   delete d;
 }
 
@@ -1576,9 +1654,17 @@ int relate_distance_get_topology_with_repaint(relate_distance* d, int snp, void*
   if (int rc = relate_plan_repaint_layout(p, d->section, &rows, &pitch, d->row_offsets.data())) return rc;
   if (int rc = d->topology.reserve(sizeof(float) * (size_t)rows * (size_t)pitch)) return rc;
   if (int rc = d->logscales.reserve(sizeof(float) * (size_t)rows)) return rc;
+  if (d->ls_pending) {  // the previous section's copy may still be writing the block that is about to grow
+    HIP_TRY(hipEventSynchronize(d->ls_fetched));
+    d->ls_pending = false;
+  }
+  if (int rc = d->h_logscales.reserve(sizeof(float) * (size_t)rows)) return rc;
   const size_t R = relate_record_bytes(d->N);
   if (int rc = relate_plan_repaint(p, d->section, d->d_stones + (size_t)d->section * d->N * R, d->topology.p, d->logscales.p, stream))
     return rc;
+  HIP_TRY(hipMemcpyAsync(d->h_logscales.p, d->logscales.p, sizeof(float) * (size_t)rows, hipMemcpyDeviceToHost, p->pick(stream)));
+  HIP_TRY(hipEventRecord(d->ls_fetched, p->pick(stream)));
+  d->ls_pending = true;
   d->rows = rows;
   d->pitch = pitch;
   d->section_startpos = start;
@@ -1639,8 +1725,14 @@ int relate_distance_get_matrix(relate_distance* d, int snp, void* d_matrix, void
       d->weight_right[(size_t)n] = (d->rpos[(size_t)snp] - rp) / denom;
     }
   }
-  return relate_plan_distance_matrix(d->plan, N, d->topology.p, d->pitch, d->logscales.p, d->rows, d->row_index.data(),
-                                     d->interpolate.data(), d->weight_left.data(), d->weight_right.data(), d_matrix, stream);
+  if (d->ls_pending) {
+    HIP_TRY(hipSetDevice(d->plan->device));
+    HIP_TRY(hipEventSynchronize(d->ls_fetched));
+    d->ls_pending = false;
+  }
+  return plan_distance_matrix(d->plan, N, d->topology.p, d->pitch, d->logscales.p, d->h_logscales.as<float>(), d->rows,
+                              d->row_index.data(), d->interpolate.data(), d->weight_left.data(), d->weight_right.data(),
+                              d_matrix, stream);
 }
 
 int relate_distance_state(const relate_distance* d, int* section, int* section_startpos, int* section_endpos,

@@ -216,40 +216,61 @@ def paint_chunk_distributed(output_dir, chunk_index, theta=None, rho=None, backe
     N, L, wb = read_parameters(output_dir, chunk_index)
     W = len(wb) - 1
     theta_v = 0.001 if theta is None else float(theta)  # Data's default, src/data.cpp:97
-    packed = backend.packed_tensor(N, L)
-    d_r = backend.r_tensor(L)
-    if rank == 0:
-        seq, r = read_chunk(output_dir, chunk_index)
-        if rho is not None:
-            r = r * float(rho)
-        backend.pack(seq, r, wb, packed, d_r)
-    dist.broadcast(packed, src=0)
-    dist.broadcast(d_r, src=0)
-    if rank != 0:
-        backend.adopt(N, L, wb, packed, d_r)
     paint_dir = os.path.join(str(output_dir), f"chunk_{chunk_index}", "paint")
     finals = [os.path.join(paint_dir, f"relate_{w}.bin") for w in range(W)]
     parts = [f + ".part" for f in finals]
-    if rank == 0:
-        os.makedirs(paint_dir, exist_ok=True)
-        for f, p in zip(finals, parts):  # "wb" in pipeline/Paint.cpp:74: nothing of an earlier run survives
-            if os.path.exists(f):
-                os.unlink(f)
-            with open(p, "wb"):
-                pass
-    dist.barrier()
-    if balance and world > 1:
-        bounds = shard_by_work(backend.derived_counts(), world)
-        k0, k1 = int(bounds[rank]), int(bounds[rank + 1])
-    else:
-        k0, k1 = shard_range(N, rank, world)
+    # Every step that can fail on one rank alone sits between collectives that all ranks reach: a rank that fails
+    # keeps taking part in them (with whatever its buffers hold) and reports through the all_reduce at the end, so
+    # no rank is left waiting in a collective and every rank raises.
     ok, err = 1, None
+
+    def attempt(step):
+        nonlocal ok, err
+        if not ok:
+            return None
+        try:
+            return step()
+        except Exception as e:  # reported to every rank below
+            ok, err = 0, e
+            return None
+
+    bufs = attempt(lambda: (backend.packed_tensor(N, L), backend.r_tensor(L)))
+    if bufs is None:  # without its buffers a rank cannot take part in the broadcast: fail before any collective
+        raise RuntimeError(f"painting of chunk {chunk_index} failed on rank {rank} before the hand-off: {err}")
+    packed, d_r = bufs
+    if rank == 0:
+        def load():
+            seq, r = read_chunk(output_dir, chunk_index)
+            if rho is not None:
+                r = r * float(rho)
+            backend.pack(seq, r, wb, packed, d_r)
+        attempt(load)
+    dist.broadcast(packed, src=0)
+    dist.broadcast(d_r, src=0)
+    if rank != 0:
+        attempt(lambda: backend.adopt(N, L, wb, packed, d_r))
+    if rank == 0:
+        def create():
+            os.makedirs(paint_dir, exist_ok=True)
+            for f, p in zip(finals, parts):  # "wb" in pipeline/Paint.cpp:74: nothing of an earlier run survives
+                if os.path.exists(f):
+                    os.unlink(f)
+                with open(p, "wb"):
+                    pass
+        attempt(create)
+    dist.barrier()
+    k0, k1 = shard_range(N, rank, world)
+    if balance and world > 1:
+        b = attempt(lambda: shard_by_work(backend.derived_counts(), world))
+        if b is not None:
+            k0, k1 = int(b[rank]), int(b[rank + 1])
     fds = []
     try:
-        fds = [os.open(p, os.O_WRONLY) for p in parts]
-        if k1 > k0:
-            backend.paint_to_files(theta_v, theta_v, k0, k1, fds)
-    except Exception as e:  # reported to every rank below
+        if ok:
+            fds = [os.open(p, os.O_WRONLY) for p in parts]
+            if k1 > k0:
+                backend.paint_to_files(theta_v, theta_v, k0, k1, fds)
+    except Exception as e:
         ok, err = 0, e
     finally:
         for fd in fds:

@@ -41,6 +41,24 @@ class _PaintLib:
         h.restype = C.c_float
         h.argtypes = [C.c_float]
         self.fast_log = h
+        # the compiled reference keeps its Data between calls behind a handle (ref_data_*); the restatement
+        # works on the caller's arrays directly and needs none
+        self._handles = hasattr(self.lib, prefix + "_data_new")
+        if self._handles:
+            n = getattr(self.lib, prefix + "_data_new")
+            n.restype = C.c_void_p
+            n.argtypes = [C.c_int, C.c_int, _u8p, _f64p, C.c_double]
+            fr = getattr(self.lib, prefix + "_data_free")
+            fr.restype = None
+            fr.argtypes = [C.c_void_p]
+            ps = getattr(self.lib, prefix + "_data_paint_stones")
+            ps.restype = C.c_int
+            ps.argtypes = [C.c_void_p, C.c_double, C.c_int, _i32p, C.c_int, C.c_int, _u8p]
+            self._new, self._free, self._paint_h = n, fr, ps
+
+    def open_chunk(self, seq, r, theta_d):
+        """A chunk kept by the library between paint_stones calls (no copy of the matrix per call)."""
+        return _Chunk(self, seq, r, theta_d)
 
     def paint_stones(self, seq, r, theta_p, theta_d, wb, k_begin=0, k_end=None):
         """seq: (L,N) uint8 of '0'/'1'; returns (W, K, 56+8N) uint8."""
@@ -71,6 +89,38 @@ class _PaintLib:
         if nd < 0:
             raise RuntimeError("repaint_section failed")
         return top[:nd].copy(), ls[:nd].copy()
+
+
+class _Chunk:
+    def __init__(self, lib, seq, r, theta_d):
+        self.lib = lib
+        self.seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        self.r = np.ascontiguousarray(r, dtype=np.float64)
+        self.theta_d = theta_d
+        self.L, self.N = self.seq.shape
+        self.h = None
+        if lib._handles:
+            self.h = lib._new(self.N, self.L, _ptr(self.seq, _u8p), _ptr(self.r, _f64p), theta_d)
+
+    def paint_stones(self, theta_p, wb, k_begin, k_end):
+        wb = np.ascontiguousarray(wb, dtype=np.int32)
+        W = len(wb) - 1
+        out = np.zeros((W, k_end - k_begin, record_size(self.N)), dtype=np.uint8)
+        if self.h is not None:
+            rc = self.lib._paint_h(self.h, theta_p, W, _ptr(wb, _i32p), k_begin, k_end, _ptr(out, _u8p))
+        else:
+            rc = self.lib._paint(self.N, self.L, _ptr(self.seq, _u8p), _ptr(self.r, _f64p), theta_p, self.theta_d, W,
+                                 _ptr(wb, _i32p), k_begin, k_end, _ptr(out, _u8p))
+        if rc != 0:
+            raise RuntimeError(f"paint_stones failed: {rc}")
+        return out
+
+    def close(self):
+        if self.h is not None:
+            self.lib._free(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 def build_oracle():
@@ -130,6 +180,15 @@ def ref():
     if _ref is None:
         _ref = _PaintLib(os.path.join(ORACLE_DIR, "_ref", "libpaint_ref.so"), "ref")
     return _ref
+
+
+def fast_build(kind):
+    """The -O3 / AVX2 build of the compiled reference ("reference") or of the restatement ("port"), or None."""
+    path = (os.path.join(ORACLE_DIR, "_ref", "libpaint_ref_o3.so") if kind == "reference"
+            else os.path.join(ORACLE_DIR, "libpaint_oracle_o3.so"))
+    if not os.path.exists(path):
+        return None
+    return _PaintLib(path, "ref" if kind == "reference" else "oracle")
 
 
 # ---- record decoding -------------------------------------------------------

@@ -153,6 +153,51 @@ def test_c5_10000_haplotypes_skewed_map_in_batches():
     plan.close()
 
 
+@pytest.mark.timeout(1500)
+def test_c4_20000_haplotypes_100k_snps_in_batches():
+    """20 000 haplotypes x 100 000 SNPs at full length on one GPU: windows by the reference's memory rule with
+    --memory 40 (src/data.cpp:145-155,:235-245: 400 windows, 64 MB of records per target, 1.28 TB in all), painted
+    in batches of targets whose records fit HBM.  Every record of every batch is checked on the device; one or
+    two targets per batch (first and last of a batch, word and wave edges, random ones) come back and are
+    compared with the oracle."""
+    import torch
+    import relate_amd as ra
+    N, L = 20000, 100000
+    seq, r = ra.synth_chunk(N, L, 4)
+    wb = ra.window_boundaries(seq, memory_gb=40.0)
+    W, R = len(wb) - 1, ra.record_bytes(N)
+    assert 300 <= W <= 500
+    d_seq = torch.from_numpy(seq).cuda()
+    d_r = torch.from_numpy(r).cuda()
+    kb = 1250  # 80 GB of records per batch
+    out = torch.empty(W * kb * R, dtype=torch.uint8, device="cuda")
+    plan = ra.Plan(0)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, st)
+    rng = np.random.default_rng(4)
+    # targets at the edges of words (64), of the lanes' words per wave (8 waves x 40 words: 2560) and of batches
+    fixed = {0, 63, 64, 1249, 1250, 2559, 2560, 10239, 10240, 17919, 17920, 19999}
+    total_nd, ms = 0, 0.0
+    compared = 0
+    for k0 in range(0, N, kb):
+        k1 = min(N, k0 + kb)
+        total_nd += plan.prepare(0.001, 0.001, k0, k1, st)
+        plan.paint(out.data_ptr(), st)
+        ms += plan.timings()["paint_ms"]
+        torch.cuda.synchronize()
+        out3 = out[: W * (k1 - k0) * R].view(W, k1 - k0, R)
+        device_structure_checks(torch, out3, d_seq, wb, N, L, k0)
+        picks = sorted({k for k in fixed if k0 <= k < k1} | {int(rng.integers(k0, k1))})
+        sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, k0, picks, f"c4 N=20000 L=100000 batch from {k0}", 0.0)
+        compared += len(picks)
+    assert compared >= 12 + N // kb
+    assert total_nd == int(ol.count_derived(seq).sum())
+    g = plan.geometry()
+    _note(f"c4 N=20000 L=100000 W={W}: {N // kb} batches, recursion {ms:.0f} ms in all, "
+          f"{2.0 * (N - 1) * total_nd / (ms * 1e-3):.3e} state updates/s, geometry {g['waves_per_target']} x {g['states_per_lane']}")
+    plan.close()
+
+
 @pytest.mark.timeout(600)
 def test_20000_haplotypes_several_windows():
     """The width of the sharded configuration (eight waves per target) over a list of hundreds of sites and

@@ -63,6 +63,42 @@ def test_chunk_from_bit_rows_equals_chunk_from_bytes(tmp_path, N, L, rho):
     assert compare_records(outs[0], want, N, f"N={N} from bit rows") == 0.0
 
 
+def test_config1_200_haplotypes_5mb_from_haps_files(tmp_path):
+    """The shape of the reference's own CPU-runnable case (200 haplotypes, 5 Mb, mu = 1.25e-8, Ne = 30 000: about
+    4 Ne mu L H(199) = 44 000 SNPs, flat 1 cM/Mb map) written as .haps / .sample / .map, read by relate_haps_*,
+    painted from the bit rows, all 200 targets against the oracle."""
+    import torch
+    import relate_amd as ra
+    from relate_amd.haps import Haps
+    from test_haps_loader import write_data_set
+    N, L = 200, 44000
+    rng = np.random.default_rng(1)
+    seq, _ = ra.synth_chunk(N, L, 1)
+    gaps = rng.geometric(L / 5.0e6, L)  # mean spacing 5 Mb / L
+    bp = np.cumsum(gaps).astype(np.int64)
+    map_bp = np.linspace(0, int(bp[-1]) + 1000, 50).astype(np.int64)
+    map_cm = map_bp * 1e-6  # 1 cM per Mb
+    haps, sample, gmap, _ = write_data_set(str(tmp_path), seq, bp, rng, map_bp, map_cm)
+    with Haps(haps, sample, gmap, 5.0) as h:  # the reference's default --memory
+        assert (h.N, h.L, h.num_chunks) == (N, L, 1)
+        first, lc, wb = h.chunk(0)
+        assert (first, lc) == (0, L) and wb[0] == 0 and wb[-1] == L
+        _, _, rpos, r = h.positions()
+        assert np.array_equal(r, np.maximum(np.diff(rpos), 1e-10) * 2500)  # src/data.cpp:484-488
+        plan = ra.Plan(0)
+        h.load_chunk(plan, 0)
+    W, R = len(wb) - 1, ra.record_bytes(N)
+    out = torch.empty(W * N * R, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    plan.prepare(0.001, 0.001, 0, N, st)
+    plan.paint(out.data_ptr(), st)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(W, N, R)
+    plan.close()
+    want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb)
+    assert compare_records(got, want, N, "config 1 (200 haplotypes, 5 Mb) from .haps") == 0.0
+
+
 def test_rows_of_the_wrong_shape_are_refused():
     import relate_amd as ra
     p = ra.Plan(0)
