@@ -188,7 +188,13 @@ def test_c4_20000_haplotypes_100k_snps_in_batches():
         out3 = out[: W * (k1 - k0) * R].view(W, k1 - k0, R)
         device_structure_checks(torch, out3, d_seq, wb, N, L, k0)
         picks = sorted({k for k in fixed if k0 <= k < k1} | {int(rng.integers(k0, k1))})
-        sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, k0, picks, f"c4 N=20000 L=100000 batch from {k0}", 0.0)
+        # At this width a target's 16 million stored floats are not all the oracle's: the GPU sums 20 000 states
+        # as a tree where the reference adds them one after the other, the doubles differ in their last bits, and
+        # now and then one of them lies on the other side of a float rounding boundary.  Many states of a stone
+        # hold the same double (all that mismatched at the same recent site), so one such event shows as a few
+        # dozen floats one ulp off (measured: target 2428, 77 floats = two doubles, in two of 400 stones; the
+        # other sampled targets none).  The bar stays 1e-5 relative on every value (compare_records).
+        sampled_against_oracle(torch, out3, seq, r, wb, 0.001, 0.001, k0, picks, f"c4 N=20000 L=100000 batch from {k0}", 1e-4)
         compared += len(picks)
     assert compared >= 12 + N // kb
     assert total_nd == int(ol.count_derived(seq).sum())

@@ -4,6 +4,8 @@ gfx950 assembly statement per kernel geometry (MPL words per lane, G waves per t
 
     python3 tools/gen_paint_loop.py > relate_amd/csrc/paint_loop_gen.hpp      (the Makefile does this)
 
+tools/emu_paint_loop.py imports this module and interprets loop_body() on the CPU with every address checked.
+
 Why generated text: every value the loop carries from site to site lives in a register that is named by number
 (states, sums, pointers, the prefetched row words and gap terms), the sweep over the MPL words is unrolled, and the
 order of the instructions is the schedule (where the scalar fetches are issued relative to the single wait that
@@ -130,6 +132,15 @@ def sload(ptr, first, nw):
             done += 4
     assert 2 * done <= 2 * B + 0 or True
     return out
+
+
+def fetch_record():
+    """The record at s[REC] into its landing registers (coef, nx, dk two steps up, dk two steps down), and the
+    pointer on to the next record of the pass: what the loop expects to be on its way when it is entered."""
+    return [f"s_load_dwordx4 s[{S['RECBUF']}:{S['RECBUF'] + 3}], {sp('REC')}, 0",
+            f"s_load_dwordx2 s[{S['DKF']}:{S['DKF'] + 1}], {sp('REC')}, 16",
+            f"s_add_u32 {s1('REC')}, {s1('REC')}, {s1('RECSTEP')}",
+            f"s_addc_u32 {s1('REC', 1)}, {s1('REC', 1)}, {s1('RECSTEP', 1)}"]
 
 
 DPP = [("quad_perm:[1,0,3,2]", "0xf"), ("quad_perm:[2,3,0,1]", "0xf"), ("row_half_mirror", "0xf"), ("row_mirror", "0xf")]
@@ -271,10 +282,12 @@ def loop_body(mpl, G):
             o += sload("RP", rr[r + 1][0], rr[r + 1][1])
         else:
             o += sload("RPNEXT", rr[0][0], rr[0][1])
-            o += [f"s_load_dwordx4 s[{S['RECBUF']}:{S['RECBUF'] + 3}], {sp('REC')}, 0",
-                  f"s_load_dwordx2 s[{S['DKF']}:{S['DKF'] + 1}], {sp('REC')}, 16",
-                  f"s_add_u32 {s1('REC')}, {s1('REC')}, {s1('RECSTEP')}",
-                  f"s_addc_u32 {s1('REC', 1)}, {s1('REC', 1)}, {s1('RECSTEP', 1)}",
+            # the record of the site after the next one; the last site of a pass has none (its list ends there:
+            # one record further lies outside the target's list, for the first or last target outside the buffer)
+            o += [f"s_cmp_eq_u32 {s1('LEFT')}, 0",
+                  "s_cbranch_scc1 .Lnorec%="]
+            o += fetch_record()
+            o += [".Lnorec%=:",
                   f"s_mul_hi_u32 {s1('TMP', 1)}, {s1('DK2')}, {s1('STRIDE')}",
                   f"s_mul_i32 {s1('TMP')}, {s1('DK2')}, {s1('STRIDE')}",
                   f"s_add_u32 {s1('TMP')}, {s1('TMP')}, {s1('ROWSW')}",
