@@ -112,9 +112,7 @@ typedef struct relate_plan relate_plan;
 
 int relate_plan_create(int device, relate_plan** out);
 void relate_plan_destroy(relate_plan* p);
-/* Kernel choice: variant 1 = register-resident recursion (default), 2 = the same recursion with the site loop of
- * a pass written as one assembly statement (fewer registers per lane, more waves in flight; painter and data
- * must hold one theta, otherwise variant 1's kernels run), 0 = plain HIP cross-check (N <= 4096);
+/* Kernel choice: variant 1 = register-resident recursion (default), 0 = plain HIP cross-check (N <= 4096);
  * waves_per_target 0 = automatic, else 1/2/4/8.  Call relate_plan_prepare again after changing it. */
 int relate_plan_configure(relate_plan* p, int variant, int waves_per_target);
 

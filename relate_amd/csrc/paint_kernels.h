@@ -86,8 +86,7 @@ hipError_t launch_section_last_terms(const int32_t* d_dk, const int64_t* d_off, 
                                      hipStream_t st);
 hipError_t launch_window_stones(const int32_t* d_dk, const int64_t* d_off, const int32_t* d_nd, int K, int W,
                                 const int32_t* d_wb, int32_t* d_bbj, int32_t* d_bej, hipStream_t st);
-// variant: 0 = plain HIP recursion (cross-check, N <= 4096), 1 = register-resident recursion, 2 = the same with
-// the steady-state loop of a pass as one generated assembly statement (one theta; two thetas run variant 1's kernels)
+// variant: 0 = plain HIP recursion (cross-check, N <= 4096), 1 = register-resident recursion
 hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStream_t st);
 hipError_t launch_fast_log(const float* d_in, float* d_out, int n, hipStream_t st);
 // DistanceMeasure::GetMatrix (src/anc_builder.cpp:113-211) on a device-resident topology: row n of `matrix`

@@ -819,12 +819,6 @@ hipError_t launch_paint_regs_g2(const PaintArgs& a, int MPL, hipStream_t st);
 hipError_t launch_paint_regs_g4(const PaintArgs& a, int MPL, hipStream_t st);
 hipError_t launch_paint_regs_g8(const PaintArgs& a, int MPL, hipStream_t st);
 
-// defined in paint_loop_g*.hip
-hipError_t launch_paint_loop_g1(const PaintArgs& a, int MPL, hipStream_t st);
-hipError_t launch_paint_loop_g2(const PaintArgs& a, int MPL, hipStream_t st);
-hipError_t launch_paint_loop_g4(const PaintArgs& a, int MPL, hipStream_t st);
-hipError_t launch_paint_loop_g8(const PaintArgs& a, int MPL, hipStream_t st);
-
 #define RELATE_PLAIN_CASE(M, GG) \
   if (g.MPL == M && g.G == GG) return launch_plain_t<M, GG>(a, st);
 
@@ -839,19 +833,8 @@ hipError_t launch_paint(const PaintArgs& a, PaintGeometry g, int variant, hipStr
     RELATE_PLAIN_CASE(1, 4) RELATE_PLAIN_CASE(4, 4) RELATE_PLAIN_CASE(16, 4)
     return hipErrorInvalidValue;
   }
-  if (variant != 1 && variant != 2) return hipErrorInvalidValue;
+  if (variant != 1) return hipErrorInvalidValue;
   if (g.G * g.MPL > a.row_stride || !a.rec) return hipErrorInvalidValue;
-  // variant 2: the steady-state loop in assembly; it exists for one emission probability (painter and data hold
-  // the same theta), the two-theta case takes the kernels of variant 1
-  if (variant == 2 && a.c.same_theta) {
-    switch (g.G) {
-      case 1: return launch_paint_loop_g1(a, g.MPL, st);
-      case 2: return launch_paint_loop_g2(a, g.MPL, st);
-      case 4: return launch_paint_loop_g4(a, g.MPL, st);
-      case 8: return launch_paint_loop_g8(a, g.MPL, st);
-      default: return hipErrorInvalidValue;
-    }
-  }
   switch (g.G) {
     case 1: return launch_paint_regs_g1(a, g.MPL, st);
     case 2: return launch_paint_regs_g2(a, g.MPL, st);

@@ -295,7 +295,7 @@ void relate_plan_destroy(relate_plan* p)
 int relate_plan_configure(relate_plan* p, int variant, int waves_per_target)
 {
   if (!p) return fail(RELATE_EINVAL, "null plan");
-  if (variant != 0 && variant != 1 && variant != 2) return fail(RELATE_EINVAL, "variant must be 0, 1 or 2");
+  if (variant != 0 && variant != 1) return fail(RELATE_EINVAL, "variant must be 0 or 1");
   if (waves_per_target != 0 && waves_per_target != 1 && waves_per_target != 2 && waves_per_target != 4 &&
       waves_per_target != 8)
     return fail(RELATE_EINVAL, "waves_per_target must be 0, 1, 2, 4 or 8");
@@ -615,7 +615,7 @@ int relate_plan_repaint_layout(relate_plan* p, int window, int64_t* total_rows, 
   if (!p) return fail(RELATE_EINVAL, "null plan");
   if (p->K <= 0 || !p->have_prepare) return fail(RELATE_EINVAL, "no targets prepared");
   if (int rc = stone_indices_on_host(p)) return rc;
-  if (p->variant < 1) return fail(RELATE_EINVAL, "re-painting needs the register-resident kernels (variant 1 or 2)");
+  if (p->variant != 1) return fail(RELATE_EINVAL, "re-painting needs the register-resident kernel (variant 1)");
   if (window < 0 || window >= p->W) return fail(RELATE_EINVAL, "window out of range");
   int64_t rows = 0;
   for (int t = 0; t < p->K; t++) {
