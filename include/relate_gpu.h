@@ -222,6 +222,46 @@ int relate_distance_get_matrix(relate_distance* d, int snp, void* d_matrix, void
 /* The bookkeeping as it stands (any pointer may be NULL; the vectors have N entries). */
 int relate_distance_state(const relate_distance* d, int* section, int* section_startpos, int* section_endpos,
                           int64_t* v_snp_prev, double* v_rpos_prev, double* v_rpos_next);
+/* ------------------------------------------------------------------------
+ * The tree builder's opening scans over the distance matrix:
+ *   void MinMatch::Initialize(CollapsedMatrix<float>& d, std::uniform_real_distribution<double>& dist_unif)
+ *   (src/tree_builder.cpp:57-127; with sample ages :130-214; declared src/tree_builder.hpp:71-72), called by
+ *   MinMatch::QuickBuild (:1003, :928) on the matrix DistanceMeasure::GetMatrix has just filled.
+ * Its two passes over the N x N matrix run on the device, on the matrix where relate_distance_get_matrix /
+ * relate_plan_distance_matrix left it:
+ *   min_values[i] = min over l != i of d[i][l], + threshold                               (:64-78)
+ *   the pairs i < j with min_values[i] >= d[i][j] and min_values[j] >= d[j][i]            (:81-91)
+ * and the pairs come back compacted, in the order of the reference's double loop (i ascending, then j
+ * ascending), each with sym_dist = d[i][j] + d[j][i] (:95).  What stays on the host is the part that is
+ * sequential by construction: one draw of the caller's generator per pair, in that order (rng.seed(1), :852),
+ * and the bookkeeping of mcandidates / best_candidate (:96-114), which relate_minmatch_apply_candidates does
+ * with the caller's generator behind a callback.  The coalescence loop itself (Coalesce, :258-475) is not part
+ * of this library.
+ * threshold: MinMatch's, -0.2 * log(theta / (1 - theta)) as a float (:43) = relate_minmatch_threshold(theta).
+ * min_values: N floats (host).  cand_i / cand_j / cand_dist: `capacity` entries each (host); *count receives
+ * the number of pairs.  If there are more pairs than `capacity`, nothing is stored, *count still holds the
+ * number and the call returns RELATE_ERANGE: call again with larger arrays.  The call waits for `stream`.
+ * ------------------------------------------------------------------------ */
+float relate_minmatch_threshold(double theta);
+int relate_plan_minmatch_scan(relate_plan* p, int N, const void* d_matrix, float threshold, float* min_values,
+                              int64_t capacity, int32_t* cand_i, int32_t* cand_j, float* cand_dist, int64_t* count,
+                              void* stream);
+/* struct Candidate (src/tree_builder.hpp:12-25) as plain data. */
+typedef struct relate_candidate {
+  int32_t lin1, lin2;
+  double dist, dist2, dist3;
+  int32_t replace;
+} relate_candidate;
+/* The rest of Initialize on the host: for every pair of the list, in order, one call of draw(draw_ctx) (the
+ * caller's dist_unif(rng)) and the updates of mcandidates[i], mcandidates[j] and best_candidate
+ * (:96-114; sample_ages != NULL: :169-200 with the caller's current `age`, :926).  mcandidates: N entries, whose
+ * dist / dist2 (and dist3 / replace with sample ages) are reset first, as :66-67 / :139-142 do; best: the
+ * caller's best_candidate, updated in place (QuickBuild sets its distances to infinity before, :889-891). */
+int relate_minmatch_apply_candidates(int N, int64_t count, const int32_t* cand_i, const int32_t* cand_j,
+                                     const float* cand_dist, const double* sample_ages, double age,
+                                     double (*draw)(void*), void* draw_ctx, relate_candidate* mcandidates,
+                                     relate_candidate* best);
+
 /* nd_k of every haplotype of the loaded chunk (the number of sites its list holds: its derived sites and the
  * two forced ends, src/fast_painting.cpp:60-110), N ints on the host; the cost of painting target k is
  * proportional to it.  Waits for the result. */

@@ -10,3 +10,4 @@ from ._lib import RelateError, lib, library_path, record_bytes  # noqa: F401
 from .paint import Data, FastPainting, Plan, paint_chunk, paint_stones  # noqa: F401
 from .synth import synth_chunk, window_boundaries, write_chunk  # noqa: F401
 from .topology import DistanceMeasure, NativeDistanceMeasure  # noqa: F401
+from .treebuilder import Candidate, MinMatchScan, apply_candidates, minmatch_threshold  # noqa: F401

@@ -62,6 +62,9 @@ PROTOTYPES = {
     "relate_distance_advance": (C.c_int, [vp, C.c_int]),
     "relate_distance_get_matrix": (C.c_int, [vp, C.c_int, vp, vp]),
     "relate_distance_state": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), i64p, f64p, f64p]),
+    "relate_minmatch_threshold": (C.c_float, [C.c_double]),
+    "relate_plan_minmatch_scan": (C.c_int, [vp, C.c_int, vp, C.c_float, f32p, C.c_int64, i32p, i32p, f32p, i64p, vp]),
+    "relate_minmatch_apply_candidates": (C.c_int, [C.c_int, C.c_int64, i32p, i32p, f32p, f64p, C.c_double, vp, vp, vp, vp]),
     "relate_plan_derived_counts": (C.c_int, [vp, i32p]),
     "relate_shard_by_work": (C.c_int, [C.c_int, i32p, C.c_int, i32p]),
     "relate_plan_paint_to_files": (C.c_int, [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),

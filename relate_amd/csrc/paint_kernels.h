@@ -100,6 +100,14 @@ hipError_t launch_distance_matrix(const float* d_top, int pitch, const float* d_
 hipError_t launch_gather_logscales(const float* d_ls, const int64_t* d_row, const uint8_t* d_interp, int N, float* d_out,
                                    hipStream_t st);
 
+// The scans of MinMatch::Initialize (src/tree_builder.cpp:57-127) over a device-resident N x N matrix:
+// d_min_values[N] (threshold added), d_counts[N] candidate pairs per row, d_offsets[N + 1] their exclusive prefix
+// sums (d_offsets[N] = number of pairs); then the pairs (i, j, d[i][j] + d[j][i]) in the reference's loop order.
+hipError_t launch_minmatch_scan(const float* d_matrix, int N, float threshold, float* d_min_values, int32_t* d_counts,
+                                int64_t* d_offsets, hipStream_t st);
+hipError_t launch_minmatch_fill(const float* d_matrix, int N, const float* d_min_values, const int64_t* d_offsets,
+                                int64_t capacity, int32_t* d_ci, int32_t* d_cj, float* d_cd, hipStream_t st);
+
 // Re-painting of one window from its stones (register-resident kernels, repaint_regs.hpp).
 struct RepaintLaunch {
   const uint64_t* rows;

@@ -17,6 +17,7 @@
 //
 // Compiled with -ffp-contract=off: every product and sum rounds on its own,
 // as in the reference's scalar code; fused operations appear only where written.
+#include "minmatch_kernels.hpp"
 #include "paint_device.hpp"
 #include "paint_kernels.h"
 
@@ -804,6 +805,29 @@ hipError_t launch_distance_matrix(const float* d_top, int pitch, const float* d_
   else if (N <= 256 * 40) RELATE_DM(40);
   else RELATE_DM(0);
 #undef RELATE_DM
+  return hipGetLastError();
+}
+
+// MinMatch::Initialize's scans (src/tree_builder.cpp:57-127): row minima, then candidate pairs counted per row
+// and their offsets.  d_offsets[N] is the number of pairs.
+hipError_t launch_minmatch_scan(const float* d_matrix, int N, float threshold, float* d_min_values, int32_t* d_counts,
+                                int64_t* d_offsets, hipStream_t st)
+{
+  if (N < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(minmatch::row_min_kernel, dim3(N), dim3(64), 0, st, d_matrix, N, threshold, d_min_values);
+  hipLaunchKernelGGL(minmatch::count_candidates_kernel, dim3(N), dim3(64), 0, st, d_matrix, d_min_values, N, d_counts);
+  hipLaunchKernelGGL(minmatch::scan_counts_kernel, dim3(1), dim3(minmatch::kScanThreads), 0, st, d_counts, N, d_offsets);
+  return hipGetLastError();
+}
+
+// The pairs themselves, row by row in ascending j, at the offsets of launch_minmatch_scan; at most `capacity`
+// are written.
+hipError_t launch_minmatch_fill(const float* d_matrix, int N, const float* d_min_values, const int64_t* d_offsets,
+                                int64_t capacity, int32_t* d_ci, int32_t* d_cj, float* d_cd, hipStream_t st)
+{
+  if (N < 1 || capacity < 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(minmatch::fill_candidates_kernel, dim3(N), dim3(64), 0, st, d_matrix, d_min_values, N, d_offsets,
+                     capacity, d_ci, d_cj, d_cd);
   return hipGetLastError();
 }
 

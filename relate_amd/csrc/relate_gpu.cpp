@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -185,6 +186,8 @@ struct relate_plan {
   bool have_prepare_stream = false;
   DevBuf row_off, last_coef, last_nx, scratch;
   DevBuf dm_args;  // per-row arguments of the distance-matrix kernel
+  DevBuf mm_min, mm_counts, mm_off, mm_ci, mm_cj, mm_cd;  // MinMatch scans: row minima, pair counts / offsets, the pairs
+  HostBuf h_mm;
   // page-locked staging of the small per-call arrays of repaint / distance_matrix: the upload is asynchronous, and
   // the next call waits for `staged` (the upload alone, not the kernels behind it) before it refills the block
   HostBuf h_stage;
@@ -282,9 +285,10 @@ void relate_plan_destroy(relate_plan* p)
   if (p->own_stream) (void)hipStreamSynchronize(p->own_stream);
   if (!p->packed_borrowed) p->packed.release();
   for (DevBuf* b : {&p->seq_own, &p->r_own, &p->wb_dev, &p->nd, &p->off, &p->dk, &p->coef, &p->nx, &p->bbj, &p->bej,
-                    &p->order, &p->trace, &p->rec, &p->row_off, &p->last_coef, &p->last_nx, &p->scratch, &p->dm_args})
+                    &p->order, &p->trace, &p->rec, &p->row_off, &p->last_coef, &p->last_nx, &p->scratch, &p->dm_args,
+                    &p->mm_min, &p->mm_counts, &p->mm_off, &p->mm_ci, &p->mm_cj, &p->mm_cd})
     b->release();
-  for (HostBuf* b : {&p->h_nd, &p->h_off, &p->h_order, &p->h_stage}) b->release();
+  for (HostBuf* b : {&p->h_nd, &p->h_off, &p->h_order, &p->h_stage, &p->h_mm}) b->release();
   if (p->staged) (void)hipEventDestroy(p->staged);
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
@@ -872,6 +876,118 @@ int relate_distance_matrix_noalloc(int device, int N, const void* d_topology, in
   return distance_matrix_run(N, static_cast<const float*>(d_topology), pitch, static_cast<const float*>(d_logscales), nullptr,
                              row_index, interpolate, weight_left, weight_right, g_noalloc_host, d,
                              static_cast<float*>(d_matrix), static_cast<hipStream_t>(stream), nullptr);
+}
+
+float relate_minmatch_threshold(double theta) { return (float)(-0.2 * std::log(theta / (1.0 - theta))); }
+
+int relate_plan_minmatch_scan(relate_plan* p, int N, const void* d_matrix, float threshold, float* min_values,
+                              int64_t capacity, int32_t* cand_i, int32_t* cand_j, float* cand_dist, int64_t* count,
+                              void* stream)
+{
+  if (!p || !d_matrix || !min_values || !count) return fail(RELATE_EINVAL, "null argument");
+  if (N < 1 || capacity < 0) return fail(RELATE_EINVAL, "bad matrix size or capacity");
+  if (capacity > 0 && (!cand_i || !cand_j || !cand_dist)) return fail(RELATE_EINVAL, "null candidate arrays");
+  *count = 0;
+  HIP_TRY(hipSetDevice(p->device));
+  hipStream_t st = p->pick(stream);
+  if (int rc = p->mm_min.reserve(sizeof(float) * (size_t)N)) return rc;
+  if (int rc = p->mm_counts.reserve(sizeof(int32_t) * (size_t)N)) return rc;
+  if (int rc = p->mm_off.reserve(sizeof(int64_t) * ((size_t)N + 1))) return rc;
+  HIP_TRY(hipEventRecord(p->ev[4], st));
+  HIP_TRY(relate::launch_minmatch_scan(static_cast<const float*>(d_matrix), N, threshold, p->mm_min.as<float>(),
+                                       p->mm_counts.as<int32_t>(), p->mm_off.as<int64_t>(), st));
+  // page-locked landing block: the total first, later the pairs
+  if (int rc = p->h_mm.reserve(sizeof(int64_t) + sizeof(float) * (size_t)N)) return rc;
+  int64_t* h_total = p->h_mm.as<int64_t>();
+  HIP_TRY(hipMemcpyAsync(h_total, p->mm_off.as<int64_t>() + N, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(min_values, p->mm_min.p, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const int64_t total = *h_total;
+  if (total < 0 || total > (int64_t)N * (N - 1) / 2) return fail(RELATE_EGPU, "candidate count out of range (kernel fault?)");
+  *count = total;
+  if (total > capacity)
+    return fail(RELATE_ERANGE, "the matrix has " + std::to_string(total) + " candidate pairs, the arrays hold " +
+                                   std::to_string(capacity) + ": call again with larger ones");
+  if (total > 0) {
+    if (int rc = p->mm_ci.reserve(sizeof(int32_t) * (size_t)total)) return rc;
+    if (int rc = p->mm_cj.reserve(sizeof(int32_t) * (size_t)total)) return rc;
+    if (int rc = p->mm_cd.reserve(sizeof(float) * (size_t)total)) return rc;
+    HIP_TRY(relate::launch_minmatch_fill(static_cast<const float*>(d_matrix), N, p->mm_min.as<float>(), p->mm_off.as<int64_t>(),
+                                         total, p->mm_ci.as<int32_t>(), p->mm_cj.as<int32_t>(), p->mm_cd.as<float>(), st));
+    HIP_TRY(hipMemcpyAsync(cand_i, p->mm_ci.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(cand_j, p->mm_cj.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(cand_dist, p->mm_cd.p, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipEventRecord(p->ev[5], st));
+  p->have_paint = true;
+  HIP_TRY(hipStreamSynchronize(st));
+  return RELATE_OK;
+}
+
+int relate_minmatch_apply_candidates(int N, int64_t count, const int32_t* cand_i, const int32_t* cand_j,
+                                     const float* cand_dist, const double* sample_ages, double age,
+                                     double (*draw)(void*), void* draw_ctx, relate_candidate* mcandidates,
+                                     relate_candidate* best)
+{
+  if (N < 1 || count < 0 || !draw || !mcandidates || !best) return fail(RELATE_EINVAL, "bad argument");
+  if (count > 0 && (!cand_i || !cand_j || !cand_dist)) return fail(RELATE_EINVAL, "null candidate arrays");
+  const double inf = std::numeric_limits<float>::infinity();  // Candidate's initial distances, src/tree_builder.hpp:15-17
+  // bool operator>(const Candidate&, const Candidate&), src/tree_builder.cpp:8-23
+  auto greater = [](const relate_candidate& a, const relate_candidate& b) {
+    if (a.replace && a.dist3 >= b.dist3) {
+      if (a.dist3 > b.dist3) return true;
+      if (a.dist > b.dist || (a.dist == b.dist && a.dist2 > b.dist2)) return true;
+    }
+    return a.dist > b.dist || (a.dist == b.dist && a.dist2 > b.dist2);
+  };
+  for (int n = 0; n < N; n++) {  // :66-67 / :139-142
+    mcandidates[n].dist = mcandidates[n].dist2 = inf;
+    if (sample_ages) {
+      mcandidates[n].dist3 = inf;
+      mcandidates[n].replace = 0;
+    }
+  }
+  for (int64_t c = 0; c < count; c++) {
+    const int it = cand_i[c], jt = cand_j[c];
+    if (it < 0 || jt <= it || jt >= N) return fail(RELATE_EINVAL, "candidate pair out of order or out of range");
+    if (!sample_ages) {
+      const float sym_dist = cand_dist[c];
+      const float dist_random = (float)draw(draw_ctx);  // the reference keeps the draw in a float (src/tree_builder.hpp:47)
+      for (relate_candidate* m : {&mcandidates[it], &mcandidates[jt]})  // :97-108
+        if (m->dist > sym_dist || (m->dist == sym_dist && m->dist2 > dist_random)) {
+          m->lin1 = it;
+          m->lin2 = jt;
+          m->dist = sym_dist;
+          m->dist2 = dist_random;
+        }
+      const relate_candidate& mj = mcandidates[jt];
+      if (best->dist > mj.dist || (best->dist == mj.dist && best->dist2 > mj.dist2)) {  // :109-114
+        best->lin1 = it;
+        best->lin2 = jt;
+        best->dist = sym_dist;
+        best->dist2 = mj.dist2;
+      }
+    } else {
+      relate_candidate cand = {};  // :169-172
+      cand.lin1 = cand.lin2 = -1;
+      cand.dist = cand_dist[c];
+      cand.dist3 = std::max(sample_ages[it], sample_ages[jt]);
+      cand.dist2 = draw(draw_ctx);
+      for (relate_candidate* m : {&mcandidates[it], &mcandidates[jt]})  // :173-192
+        if ((m->dist == inf || cand.dist3 <= age) && greater(*m, cand)) {
+          cand.replace = cand.dist3 > age ? 1 : 0;
+          *m = cand;
+          m->lin1 = it;
+          m->lin2 = jt;
+        }
+      const relate_candidate& mj = mcandidates[jt];
+      if ((best->dist == inf || mj.dist3 <= age) && greater(*best, mj)) {  // :193-200
+        *best = mj;
+        best->replace = best->dist3 > age ? 1 : 0;
+      }
+    }
+  }
+  return RELATE_OK;
 }
 
 int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float* ms_paint)
