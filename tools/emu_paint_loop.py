@@ -505,7 +505,8 @@ def row_stride_words(N):
 class Chunk:
     """Inputs of one chunk as the library lays them out in HBM (paint_kernels.hip, relate_gpu.cpp)."""
 
-    def __init__(self, seq, r, wb, theta):
+    def __init__(self, seq, r, wb, theta, theta_d=None):
+        theta_d = theta if theta_d is None else theta_d
         self.L, self.N = seq.shape
         L, N = self.L, self.N
         self.W = len(wb) - 1
@@ -521,8 +522,8 @@ class Chunk:
         ntheta = 1.0 - theta
         self.c = dict(Nm1=Nm1, prior_mis=1.0 * (theta / Nm1 - ntheta / Nm1) + ntheta / Nm1, prior_match=ntheta / Nm1,
                       rho=1.0 * (theta / ntheta - 1.0) + 1.0, log_ntheta=math.log(ntheta), log_small=math.log(0.01),
-                      log_Nm1=math.log(Nm1), theta_d=theta, ntheta_d=ntheta, inv_theta_d=1.0 / theta,
-                      inv_ntheta_d=1.0 / ntheta, lo=1e-10, hi=1.0 / 1e-10)
+                      log_Nm1=math.log(Nm1), theta_d=theta_d, ntheta_d=1.0 - theta_d, inv_theta_d=1.0 / theta_d,
+                      inv_ntheta_d=1.0 / (1.0 - theta_d), lo=1e-10, hi=1.0 / 1e-10, same_theta=int(theta == theta_d))
         # per target lists
         self.dk, self.rec, self.off = [], [], []
         self.bbj = np.zeros((N, self.W), dtype=np.int64)
