@@ -66,13 +66,13 @@ def build_memory(ch, targets):
 UNDEFINED = {}  # (instruction index, text) -> registers read before anything wrote them
 
 
-def run_paint(asm, kernel_rx, ch, targets, G, MPL, verbose=True):
+def run_paint(asm, kernel_rx, ch, targets, G, MPL, verbose=True, garbage=None):
     kern = emu.load_kernel(asm, kernel_rx)
     mem, kernarg = build_memory(ch, targets)
     lds_bytes = G * MPL * 256 + 3 * G * 8
     stats = {}
     for block in range(2 * len(targets)):
-        waves = emu.run_workgroup(kern, mem, kernarg, block, G, lds_bytes)
+        waves = emu.run_workgroup(kern, mem, kernarg, block, G, lds_bytes, garbage=None if garbage is None else garbage + block)
         for w in waves:
             for k, v in w.stats.items():
                 stats[k] = stats.get(k, 0) + v
@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--waves", type=int, default=1)
     ap.add_argument("--mpl", type=int, default=4)
     ap.add_argument("--targets", default="0:2")
+    ap.add_argument("--garbage", type=int, default=None, help="seed: registers, LDS and scratch start with random contents")
     args = ap.parse_args()
     g = load_golden(args.golden)
     a, b = (int(v) for v in args.targets.split(":"))
@@ -112,7 +113,7 @@ def main():
     ch = lists.Chunk(g["seq"], g["r"], g["wb"], g["theta_painter"], g["theta_data"])
     rx = args.kernel or rf"paint_kernel_rILi{args.mpl}ELi{args.waves}E"
     try:
-        out, stats, kern = run_paint(args.asm, rx, ch, targets, args.waves, args.mpl)
+        out, stats, kern = run_paint(args.asm, rx, ch, targets, args.waves, args.mpl, garbage=args.garbage)
     except emu.EmuError as e:
         print("FAULT:", e)
         sys.exit(1)

@@ -229,6 +229,10 @@ class Wave:
     def vsrc32(self, tok):
         """32-bit vector source as uint32[64]"""
         tok = tok.strip()
+        if tok.startswith("-") and tok[1:2] in ("v", "s", "|"):  # float negation of a register operand: the sign bit
+            return self.vsrc32(tok[1:]) ^ np.uint32(0x80000000)
+        if tok.startswith("|") and tok.endswith("|"):
+            return self.vsrc32(tok[1:-1]) & np.uint32(0x7FFFFFFF)
         r = self.vreg(tok)
         if r is not None:
             self._vread(r, 1)
@@ -734,6 +738,141 @@ class Wave:
     def op_v_mad_u32_u24(self, d, a, b, c):
         self._vi(d, lambda x, y, z: (x & np.uint64(0xFFFFFF)) * (y & np.uint64(0xFFFFFF)) + z, a, b, c)
 
+    def op_v_mad_u64_u32(self, d, carry, a, b, c):
+        x, y, z = self.vsrc32(a).astype(object), self.vsrc32(b).astype(object), self.vsrc64(c).astype(object)
+        r = x * y + z
+        self.put_lanemask(carry, np.array([int(v) > U64 for v in r]))
+        self.put64(d, np.array([int(v) & U64 for v in r], dtype=np.uint64))
+
+    def op_v_mad_i64_i32(self, d, carry, a, b, c):
+        x = self.vsrc32(a).view(np.int32).astype(object)
+        y = self.vsrc32(b).view(np.int32).astype(object)
+        z = self.vsrc64(c).view(np.int64).astype(object)
+        r = x * y + z
+        self.put_lanemask(carry, np.array([not -(1 << 63) <= int(v) < (1 << 63) for v in r]))
+        self.put64(d, np.array([int(v) & U64 for v in r], dtype=np.uint64))
+
+    def op_v_bcnt_u32_b32(self, d, a, b):
+        x = self.vsrc32(a)
+        self.put32(d, np.array([bin(int(v)).count("1") for v in x], dtype=np.uint32) + self.vsrc32(b))
+
+    def op_v_ffbl_b32(self, d, a):
+        x = self.vsrc32(a)
+        self.put32(d, np.array([((int(v) & -int(v)).bit_length() - 1) & U32 if v else U32 for v in x], dtype=np.uint32))
+
+    def op_v_ffbh_u32(self, d, a):
+        x = self.vsrc32(a)
+        self.put32(d, np.array([32 - int(v).bit_length() if v else U32 for v in x], dtype=np.uint32))
+
+    def op_v_min_u32(self, d, a, b): self.put32(d, np.minimum(self.vsrc32(a), self.vsrc32(b)))
+    def op_v_max_u32(self, d, a, b): self.put32(d, np.maximum(self.vsrc32(a), self.vsrc32(b)))
+    def op_v_min_i32(self, d, a, b): self.put32(d, np.minimum(self.vsrc32(a).view(np.int32), self.vsrc32(b).view(np.int32)).view(np.uint32))
+    def op_v_max_i32(self, d, a, b): self.put32(d, np.maximum(self.vsrc32(a).view(np.int32), self.vsrc32(b).view(np.int32)).view(np.uint32))
+    def op_v_min_f32(self, d, a, b): self.put_f32(d, np.fmin(self.vsrc_f32(a), self.vsrc_f32(b)))
+    def op_v_max_f32(self, d, a, b): self.put_f32(d, np.fmax(self.vsrc_f32(a), self.vsrc_f32(b)))
+
+    def op_v_xad_u32(self, d, a, b, c): self._vi(d, lambda x, y, z: (x ^ y) + z, a, b, c)
+
+    def op_v_mul_i32_i24(self, d, a, b):
+        def s24(x):
+            x = x.astype(np.int64) & 0xFFFFFF
+            return np.where(x & 0x800000, x - 0x1000000, x)
+        self.put32(d, ((s24(self.vsrc32(a)) * s24(self.vsrc32(b))) & U32).astype(np.uint32))
+
+    def op_v_bfrev_b32(self, d, a):
+        self.put32(d, np.array([int(f"{int(v):032b}"[::-1], 2) for v in self.vsrc32(a)], dtype=np.uint32))
+
+    def op_v_ashrrev_i64(self, d, a, b):
+        sh = (self.vsrc32(a) & 63).astype(np.int64)
+        self.put64(d, (self.vsrc64(b).view(np.int64) >> sh).view(np.uint64))
+
+    def op_v_cmp_ne_u16(self, dst, a, b):
+        self.put_lanemask(dst, (self.vsrc32(a) & 0xFFFF) != (self.vsrc32(b) & 0xFFFF))
+
+    def op_v_cmp_eq_u16(self, dst, a, b):
+        self.put_lanemask(dst, (self.vsrc32(a) & 0xFFFF) == (self.vsrc32(b) & 0xFFFF))
+
+    def op_v_add_u32_sdwa(self, d, a, b_and_mods):
+        parts = b_and_mods.split()
+        sel = {p.split(":")[0]: p.split(":")[1] for p in parts[1:]}
+        if sel.get("dst_sel", "DWORD") != "DWORD":
+            raise EmuError("SDWA destination selection not modelled: " + self.line)
+
+        def pick(x, how):
+            if how == "DWORD":
+                return x
+            kind, idx = how.split("_")
+            if kind == "BYTE":
+                return (x >> np.uint32(8 * int(idx))) & np.uint32(0xFF)
+            if kind == "WORD":
+                return (x >> np.uint32(16 * int(idx))) & np.uint32(0xFFFF)
+            raise EmuError("SDWA selection not modelled: " + how)
+        x = pick(self.vsrc32(a), sel.get("src0_sel", "DWORD")).astype(np.uint64)
+        y = pick(self.vsrc32(parts[0]), sel.get("src1_sel", "DWORD")).astype(np.uint64)
+        self.put32(d, (x + y) & np.uint64(U32))
+
+    def op_v_fmamk_f32(self, d, a, k, b):
+        self.op_v_fma_f32(d, a, k, b)
+
+    def op_v_fmaak_f32(self, d, a, b, k):
+        self.op_v_fma_f32(d, a, b, k)
+
+    def op_v_cvt_u32_f32(self, d, a):
+        x = np.nan_to_num(np.trunc(self.vsrc_f32(a).astype(np.float64)), nan=0.0, posinf=2**32 - 1, neginf=0)
+        self.put32(d, np.clip(x, 0, 2**32 - 1).astype(np.uint64).astype(np.uint32))
+
+    def op_v_cvt_i32_f32(self, d, a):
+        x = np.nan_to_num(np.trunc(self.vsrc_f32(a).astype(np.float64)), nan=0.0, posinf=2**31 - 1, neginf=-2**31)
+        self.put32(d, np.clip(x, -2**31, 2**31 - 1).astype(np.int64).astype(np.int32).view(np.uint32))
+
+    def op_v_trunc_f32(self, d, a):
+        self.put_f32(d, np.trunc(self.vsrc_f32(a)))
+
+    def op_v_rndne_f32(self, d, a):
+        self.put_f32(d, np.rint(self.vsrc_f32(a)))
+
+    def op_v_rcp_iflag_f32(self, d, a):
+        self.op_v_rcp_f32(d, a)
+
+    def _pk_f32(self, d, a, b_and_mods, fn):
+        parts = b_and_mods.split()
+        mods = {"op_sel": [0, 0], "op_sel_hi": [1, 1], "neg_lo": [0, 0], "neg_hi": [0, 0]}
+        for p in parts[1:]:
+            k, _, v = p.partition(":")
+            mods[k] = [int(x) for x in v.strip("[]").split(",")]
+
+        def halves(tok):
+            tok = tok.strip()
+            r = self.vreg(tok)
+            if r is not None:
+                self._vread(r, 2)
+                return self.v[r].view(np.float32).copy(), self.v[r + 1].view(np.float32).copy()
+            sr = self.sreg(tok)
+            if sr is not None:
+                return (np.full(64, _f32(self.get_s32(sr)), dtype=np.float32), np.full(64, _f32(self.get_s32(sr + 1)), dtype=np.float32))
+            c = self._fconst[tok] if tok in self._fconst else _f32(int(tok, 0))
+            return np.full(64, c, dtype=np.float32), np.zeros(64, dtype=np.float32)  # a constant sits in the low half
+        x, y = halves(a), halves(parts[0])
+        out = []
+        for sel, neg in ((mods["op_sel"], mods["neg_lo"]), (mods["op_sel_hi"], mods["neg_hi"])):
+            p, q = x[sel[0]], y[sel[1]]
+            p = -p if neg[0] else p
+            q = -q if neg[1] else q
+            with np.errstate(all="ignore"):
+                out.append(fn(p, q).astype(np.float32))
+        r = self.vreg(d)
+        m = self.exec_mask()
+        self.v[r][m] = out[0].view(np.uint32)[m]
+        self.v[r + 1][m] = out[1].view(np.uint32)[m]
+        self.vdef[r] = self.vdef[r + 1] = True
+
+    def op_v_pk_add_f32(self, d, a, b): self._pk_f32(d, a, b, lambda p, q: p + q)
+    def op_v_pk_mul_f32(self, d, a, b): self._pk_f32(d, a, b, lambda p, q: p * q)
+
+    def op_v_alignbit_b32(self, d, a, b, c):
+        x = (self.vsrc32(a).astype(np.uint64) << np.uint64(32)) | self.vsrc32(b).astype(np.uint64)
+        self.put32(d, (x >> (self.vsrc32(c).astype(np.uint64) & np.uint64(31))) & np.uint64(U32))
+
     def op_v_lshl_add_u64(self, d, a, b, c):
         x, sh, z = self.vsrc64(a), self.vsrc32(b).astype(np.uint64) & np.uint64(7), self.vsrc64(c)
         with np.errstate(over="ignore"):
@@ -1218,6 +1357,29 @@ class Wave:
     def op_ds_read2st64_b32(self, d, addr, *m): self._ds_read(d, addr, self._off2((addr,) + m, 256), 1)
     def op_ds_read2st64_b64(self, d, addr, *m): self._ds_read(d, addr, self._off2((addr,) + m, 512), 2)
 
+    def op_ds_bpermute_b32(self, d, addr, data, *m):
+        """every lane fetches `data` of lane addr / 4 (mod 64); a source lane that is switched off delivers 0"""
+        ex = self.exec_mask()
+        off = self._mods((data,) + m)
+        a = self.vsrc32(addr.split()[0])
+        src = self.vsrc32(data.split()[0])
+        out = np.zeros(64, dtype=np.uint32)
+        for lane in range(64):
+            sl = ((int(a[lane]) + off) >> 2) & 63
+            out[lane] = src[sl] if ex[sl] else 0
+        self.put32(d, out)
+
+    def op_ds_permute_b32(self, d, addr, data, *m):
+        ex = self.exec_mask()
+        off = self._mods((data,) + m)
+        a = self.vsrc32(addr.split()[0])
+        src = self.vsrc32(data.split()[0])
+        out = np.zeros(64, dtype=np.uint32)
+        for lane in range(64):
+            if ex[lane]:
+                out[((int(a[lane]) + off) >> 2) & 63] = src[lane]
+        self.put32(d, out)
+
     def op_buffer_wbl2(self, *a): pass
     def op_buffer_inv(self, *a): pass
     def op_s_dcache_wb(self, *a): pass
@@ -1318,18 +1480,108 @@ def load_kernel(path, name_pattern):
     return Kernel(name, lines, labels, meta)
 
 
-def run_workgroup(kernel, mem, kernarg_addr, block_id, n_waves, lds_bytes, budget=200_000_000, on_step=None):
-    """Runs one workgroup of `n_waves` waves to completion; returns the waves (for their statistics)."""
+def kernel_args_layout(path, kernel_name):
+    """The argument list of a kernel from the code-object metadata at the end of the .s file: a list of
+    (offset, size, value_kind)."""
+    import yaml
+    text = open(path).read()
+    a = text.index(".amdgpu_metadata")
+    b = text.rindex("\n", 0, text.index(".end_amdgpu_metadata"))
+    meta = yaml.safe_load(text[a + len(".amdgpu_metadata"):b])
+    for k in meta["amdhsa.kernels"]:
+        if k[".name"] == kernel_name:
+            return [(x[".offset"], x[".size"], x[".value_kind"]) for x in k.get(".args", [])], k
+    raise KeyError(kernel_name)
+
+
+def pack_kernarg(layout, explicit, grid, block):
+    """Kernel-argument block: `explicit` (bytes objects, one per explicit argument, in order) at the offsets of
+    the metadata, the hidden arguments the device runtime would add (grid and workgroup sizes) after them."""
+    size = max(o + n for o, n, _ in layout) if layout else 0
+    buf = bytearray(size)
+    it = iter(explicit)
+    for off, n, kind in layout:
+        if not kind.startswith("hidden_"):
+            data = next(it)
+            if len(data) != n:
+                raise ValueError(f"argument at offset {off} takes {n} bytes, got {len(data)}")
+            buf[off:off + n] = data
+        elif kind.startswith("hidden_block_count_"):
+            buf[off:off + 4] = struct.pack("<I", grid["xyz".index(kind[-1])])
+        elif kind.startswith("hidden_group_size_"):
+            buf[off:off + 2] = struct.pack("<H", block["xyz".index(kind[-1])])
+        elif kind.startswith("hidden_remainder_"):
+            buf[off:off + 2] = struct.pack("<H", 0)
+        elif kind == "hidden_grid_dims":
+            buf[off:off + 2] = struct.pack("<H", 1 + (grid[1] > 1) + (grid[2] > 1))
+    if next(it, None) is not None:
+        raise ValueError("more arguments than the kernel takes")
+    return bytes(buf)
+
+
+def launch(path, name_pattern, mem, explicit, grid, block, lds_bytes=0, garbage=None):
+    """kernel<<<grid, block, lds_bytes>>>(explicit...) in the interpreter; grid and block are (x, y, z), the
+    workgroup is one-dimensional.  Returns the merged instruction statistics."""
+    kern = load_kernel(path, name_pattern)
+    layout, _ = kernel_args_layout(path, kern.name)
+    ka = pack_kernarg(layout, explicit, grid, block)
+    kernarg = mem.add("kernarg:" + kern.name[-24:], ka, max(len(ka), 8))
+    if block[1] != 1 or block[2] != 1:
+        raise ValueError("one-dimensional workgroups only")
+    stats = {}
+    n_waves = (block[0] + 63) // 64
+    for bz in range(grid[2]):
+        for by in range(grid[1]):
+            for bx in range(grid[0]):
+                waves = run_workgroup(kern, mem, kernarg, (bx, by, bz), n_waves, lds_bytes, garbage=garbage, threads=block[0])
+                for w in waves:
+                    for k, v in w.stats.items():
+                        stats[k] = stats.get(k, 0) + v
+    return stats
+
+
+def run_workgroup(kernel, mem, kernarg_addr, block_id, n_waves, lds_bytes, budget=200_000_000, on_step=None, garbage=None,
+                  threads=None):
+    """Runs one workgroup of `n_waves` waves to completion; returns the waves (for their statistics).
+    garbage: a seed; registers, LDS and scratch then start with random contents instead of zeros, as on the
+    device, where they hold what the previous wave left (a kernel whose result or addresses depend on that fails)."""
     scratch = int(kernel.meta.get("private_segment_fixed_size", "0"))
     lds = bytearray(max(lds_bytes, int(kernel.meta.get("group_segment_fixed_size", "0"))))
+    rng = np.random.default_rng(garbage) if garbage is not None else None
+    if rng is not None:
+        lds[:] = rng.integers(0, 256, len(lds), dtype=np.uint8).tobytes()
     waves = []
     for g in range(n_waves):
         w = Wave(mem, lds, len(lds), scratch, f"{kernel.name[:48]} block {block_id} wave {g}")
-        w.set_s64(0, kernarg_addr)
-        w.set_s32(2, block_id)
+        if rng is not None:
+            w.s[:102] = rng.integers(0, 1 << 32, 102, dtype=np.uint64)
+            w.s[VCC:VCC + 2] = rng.integers(0, 1 << 32, 2, dtype=np.uint64)
+            w.s[M0_REG] = int(rng.integers(0, 1 << 32))
+            w.v[:] = rng.integers(0, 1 << 32, w.v.shape, dtype=np.uint64).astype(np.uint32)
+            w.scc = int(rng.integers(0, 2))
+            for l in range(64):
+                w.scratch[l][:] = rng.integers(0, 256, scratch, dtype=np.uint8).tobytes()
+        # user SGPRs, then the system SGPRs the descriptor enables
+        ids = block_id if isinstance(block_id, tuple) else (block_id, 0, 0)
+        meta = kernel.meta
+        r = 0
+        for key, n in (("user_sgpr_dispatch_ptr", 2), ("user_sgpr_queue_ptr", 2)):
+            if meta.get(key, "0") == "1":
+                r += n  # not used by this library's kernels: left undefined
+        if meta.get("user_sgpr_kernarg_segment_ptr", "1") == "1":
+            w.set_s64(r, kernarg_addr)
+            r += 2
+        if meta.get("user_sgpr_dispatch_id", "0") == "1":
+            r += 2
+        for axis, key in enumerate(("system_sgpr_workgroup_id_x", "system_sgpr_workgroup_id_y", "system_sgpr_workgroup_id_z")):
+            if meta.get(key, "1" if axis == 0 else "0") == "1":
+                w.set_s32(r, ids[axis])
+                r += 1
         w.v[0] = (np.arange(64) + 64 * g).astype(np.uint32)
         w.vdef[0] = True
-        w.sdef[0:3] = True
+        if threads is not None and threads < 64 * (g + 1):
+            live = max(0, threads - 64 * g)
+            w.set_s64(EXEC, (1 << live) - 1)
         w.hw_id = g
         waves.append(w)
     pcs = [0] * n_waves
