@@ -34,13 +34,15 @@ using namespace dev;
 
 // ---- register map -------------------------------------------------------------------------------
 #define RELATE_CV 48  // compiler: v0..v47
-#define RELATE_CS 52  // compiler: s0..s51
-// amdgpu_num_sgpr counts the 8 special registers (VCC, FLAT_SCRATCH, XNACK_MASK) on top of s0..s51
-#define RELATE_CS_ATTR 60
+#ifndef RELATE_CS
+#define RELATE_CS 52  // compiler: s0..s51 (44: s0..s43, and 20 instead of 16 row words per round)
+#endif
+// amdgpu_num_sgpr counts the 8 special registers (VCC, FLAT_SCRATCH, XNACK_MASK) on top of the compiler's
+#define RELATE_CS_ATTR (RELATE_CS + 8)
 // amdgpu_num_vgpr is doubled by the gfx90a+ back end (unified VGPR/AGPR file); no AGPRs are used here
 #define RELATE_CV_ATTR 24
 constexpr int kCV = RELATE_CV, kCS = RELATE_CS;
-static_assert(RELATE_CS_ATTR == RELATE_CS + 8 && 2 * RELATE_CV_ATTR == RELATE_CV, "register limits");
+static_assert((RELATE_CS == 52 || RELATE_CS == 44) && 2 * RELATE_CV_ATTR == RELATE_CV, "register limits");
 constexpr int kX = kCV;       // v[kX:kX+1]   reduction operand
 constexpr int kT = kCV + 2;   // v[kT:kT+1]   scratch pair
 constexpr int kLo = kCV + 4;  // v[kLo:kLo+1] lower rescale threshold, v[kHi:kHi+1] upper
@@ -53,12 +55,14 @@ constexpr int kSelfIdx = kCS + 2;  // 2 * local word of the target's own lane
 constexpr int kPhIdx = kCS + 3;    // 2 * local word of the first padding lane (2*MPL: none)
 constexpr int kSelfM = kCS + 4;    // s[kSelfM:kSelfM+1] the target's own lane (0: another wave has it)
 constexpr int kPhM = kCS + 6;      // s[kPhM:kPhM+1] padding lanes of word kPhIdx/2
-constexpr int kBufA = kCS + 8, kBufC = kCS + 24;  // s[kBufA .. kBufA+31]: row words, as two halves of 16 registers
-constexpr int kCoefN = kCS + 40, kNxN = kCS + 42;  // prefetched per-gap terms (pairs; one 4-aligned quad)
-constexpr int kDkN = kCS + 44;  // prefetched list entry
-constexpr int kCnt = kCS + 45;  // loop counter of the padding-lane writes
-constexpr int kRec = kCS + 46;  // s[kRec:kRec+1] running pointer into the site records
-constexpr int kSkEdge = kCS + 48;  // s[kSkEdge:kSkEdge+1] the target's own allele at the forced end site of the pass, as a mask
+// s[kBufA .. 91]: row words, kBufWords of them; the two-row sweeps use them as two halves of 16 registers
+constexpr int kBufA = kCS + 8, kBufC = kBufA + 16;
+constexpr int kBufWords = (92 - kBufA) / 2;
+constexpr int kCoefN = 92, kNxN = 94;  // prefetched per-gap terms (pairs; one 4-aligned quad)
+constexpr int kDkN = 96;  // prefetched list entry
+constexpr int kCnt = 97;  // loop counter of the padding-lane writes
+constexpr int kRec = 98;  // s[kRec:kRec+1] running pointer into the site records
+constexpr int kSkEdge = 100;  // s[kSkEdge:kSkEdge+1] the target's own allele at the forced end site of the pass, as a mask
 constexpr int kMaxMPL = (256 - kA0) / 2;
 static_assert(kSkEdge + 1 <= 101 && kCoefN % 4 == 0 && kBufA % 4 == 0, "SGPR map");
 
@@ -92,14 +96,19 @@ __device__ __forceinline__ void static_for(F&& f)
 #define RELATE_VCLOB_64 RELATE_VCLOB_56, "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183"
 #define RELATE_VCLOB_72 RELATE_VCLOB_64, "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199"
 #define RELATE_VCLOB_80 RELATE_VCLOB_72, "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215"
-#define RELATE_SCLOB "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101"
+#if RELATE_CS == 44
+#define RELATE_SCLOB_LOW "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51",
+#else
+#define RELATE_SCLOB_LOW
+#endif
+#define RELATE_SCLOB RELATE_SCLOB_LOW "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101"
 template <int MPL>
 __device__ __forceinline__ void claim_registers();
 #define RELATE_CLAIM(M)                                                \
   template <>                                                          \
   __device__ __forceinline__ void claim_registers<M>()                 \
   {                                                                    \
-    asm volatile("" ::: RELATE_VCLOB_##M, RELATE_SCLOB);               \
+    asm volatile("; relate_limits v%0 s%1" ::"n"(RELATE_CV), "n"(RELATE_CS) : RELATE_VCLOB_##M, RELATE_SCLOB); \
   }
 RELATE_CLAIM(4)
 RELATE_CLAIM(8)
@@ -117,7 +126,7 @@ RELATE_CLAIM(64)
 RELATE_CLAIM(72)
 RELATE_CLAIM(80)
 #undef RELATE_CLAIM
-static_assert(kCV == 48 && kA0 == 56 && kCS == 52, "the clobber lists above are written for this register map (tools/gen_clobbers.py 48 56 52)");
+static_assert(kCV == 48 && kA0 == 56 && (kCS == 52 || kCS == 44), "the clobber lists above are written for this register map (tools/gen_clobbers.py 48 56 52)");
 
 // A wave-uniform value as an SGPR (the compiler's readfirstlane may be folded into a VGPR copy).
 __device__ __forceinline__ uint32_t sgpr32(uint32_t x)
@@ -177,7 +186,7 @@ __device__ __forceinline__ void swait() { asm volatile("s_waitcnt lgkmcnt(0)" ::
 template <int SB, int OFF, int NW>
 __device__ __forceinline__ void sload_words(const uint64_t* p)
 {
-  static_assert(NW >= 1 && NW <= 8 && (SB == kBufA || SB == kBufC), "one half of the row-word registers");
+  static_assert(NW >= 1 && NW <= 8 && SB >= kBufA && (SB - kBufA) % 16 == 0 && SB + (NW > 4 ? 16 : 8) <= 92, "a part of the row-word registers");
   if constexpr (NW > 4)
     asm volatile("s_load_dwordx16 s[%1:%1+15], %0, %2" ::"s"(p), "n"(SB), "n"(OFF) : "memory");
   else
@@ -191,7 +200,7 @@ __device__ __forceinline__ void sload_words(const uint64_t* p)
 // next site also the reduction, and a site takes as many waits as it has rounds.
 template <int MPL>
 struct RowRounds {
-  static constexpr int NR = (MPL + 15) / 16;
+  static constexpr int NR = (MPL + kBufWords - 1) / kBufWords;
   static constexpr int size(int r) { return MPL / NR + (r < MPL % NR ? 1 : 0); }
   static constexpr int first(int r)
   {
@@ -204,10 +213,11 @@ struct RowRounds {
 template <int W0, int NW>
 __device__ __forceinline__ void sload_round(const uint64_t* p)
 {
-  static_assert(NW >= 1 && NW <= 16, "one round");
+  static_assert(NW >= 1 && NW <= kBufWords, "one round");
   constexpr int na = NW < 8 ? NW : 8;
   sload_words<kBufA, 8 * W0, na>(p);
-  if constexpr (NW > 8) sload_words<kBufC, 8 * (W0 + 8), NW - 8>(p);
+  if constexpr (NW > 8) sload_words<kBufA + 16, 8 * (W0 + 8), (NW - 8 < 8 ? NW - 8 : 8)>(p);
+  if constexpr (NW > 16) sload_words<kBufA + 32, 8 * (W0 + 16), NW - 16>(p);
 }
 // The record of a list entry (SiteRec: coef, nx, dk_fwd2, dk_bwd2), fetched during a sweep for the site
 // after it.  The two list entries land in s[kDkN] (forward) and s[kCnt] (backward); the latter doubles
@@ -287,6 +297,33 @@ __device__ __forceinline__ void fetched_site(int& s, double& coef, double& nx)
   nx = __hiloint2double((int)hi1, (int)lo1);
 }
 static_assert(kCnt == kDkN + 1 && kNxN == kCoefN + 2 && sizeof(SiteRec) == 24, "record layout against the SGPR map");
+// The same values used where they arrive (the loops of several waves per target): no copies into compiler
+// registers, which are scarce there.  x * coef, ls += nx, and the row of the fetched list entry.
+__device__ __forceinline__ void set_site_terms(double coef, double nx)
+{
+  asm volatile("s_mov_b64 s[%2:%2+1], %0\n\ts_mov_b64 s[%3:%3+1], %1" ::"s"(coef), "s"(nx), "n"(kCoefN), "n"(kNxN));
+}
+__device__ __forceinline__ double times_site_coef(double x)
+{
+  double r;
+  asm volatile("v_mul_f64 %0, %1, s[%2:%2+1]" : "=v"(r) : "v"(x), "n"(kCoefN));
+  return r;
+}
+__device__ __forceinline__ void add_site_nx(double& ls) { asm volatile("v_add_f64 %0, %0, s[%1:%1+1]" : "+v"(ls) : "n"(kNxN)); }
+template <bool FWD>
+__device__ __forceinline__ const uint64_t* fetched_row_pointer(uint32_t stride_bytes)
+{
+  uint32_t lo, hi;
+  asm volatile(
+      "s_mul_hi_u32 %1, s[%2], %3\n\t"
+      "s_mul_i32 %0, s[%2], %3\n\t"
+      "s_add_u32 %0, %0, s[%4]\n\t"
+      "s_addc_u32 %1, %1, s[%4+1]"
+      : "=&s"(lo), "=&s"(hi)
+      : "n"(FWD ? kDkN : kCnt), "s"(stride_bytes), "n"(kRowsW)
+      : "scc");
+  return reinterpret_cast<const uint64_t*>(((uint64_t)hi << 32) | lo);
+}
 
 // ---- state block -----------------------------------------------------------------------------------
 template <int I>
@@ -328,12 +365,18 @@ __device__ __forceinline__ void state_unemitted_to_lds(uint32_t lds_addr, double
 // another wave; s[kSelfIdx] = 2 * local word) and every lane from the first padding lane of the wave on
 // (s[kPhM..] = lanes of that word, s[kPhIdx] = 2 * its local word; 2*MPL if the wave has none).  x*y is what the
 // sweep adds to these lanes (the product rounds like the caller's own x*y, so the sum is an exact zero).
-__device__ __forceinline__ void set_stateless(uint64_t selfm, uint32_t selfidx, uint64_t phm, uint32_t phidx)
+// Bit 31 of s[kSelfIdx] says that the wave has no such lane at all (`end_idx` = 2*MPL): write_stateless_site then
+// branches over its vector instructions.
+__device__ __forceinline__ void set_stateless(uint64_t selfm, uint32_t selfidx, uint64_t phm, uint32_t phidx, uint32_t end_idx)
 {
+  if (selfm == 0 && phidx >= end_idx) selfidx |= 0x80000000u;
   asm volatile(
       "s_mov_b64 s[%4:%4+1], %0\n\ts_mov_b32 s[%5], %1\n\ts_mov_b64 s[%6:%6+1], %2\n\ts_mov_b32 s[%7], %3" ::"s"(selfm),
       "s"(selfidx), "s"(phm), "s"(phidx), "n"(kSelfM), "n"(kSelfIdx), "n"(kPhM), "n"(kPhIdx));
 }
+#define RELATE_WRITE_STATELESS_HEAD                       \
+  "s_bitcmp1_b32 s[%[selfidx]], 31\n\t"                   \
+  "s_cbranch_scc1 .Lws_done%=\n\t"
 #define RELATE_WRITE_STATELESS_BODY                       \
   "s_mov_b64 exec, s[%[selfm]:%[selfm]+1]\n\t"            \
   "s_set_gpr_idx_on s[%[selfidx]], 8\n\t"                 \
@@ -375,6 +418,17 @@ __device__ __forceinline__ void write_stateless(double x, double y)
                  : [x] "v"(x), [y] "v"(y), RELATE_WRITE_STATELESS_REGS
                  : "scc", "memory");
 }
+// y = the fetched coefficient where it arrived (times_site_coef); a wave without such lanes (bit 31 of s[kSelfIdx],
+// see set_stateless) branches over the vector instructions
+template <int MPL>
+__device__ __forceinline__ void write_stateless_site(double x)
+{
+  asm volatile(RELATE_WRITE_STATELESS_HEAD "v_mul_f64 v[%[t]:%[t]+1], %[x], -s[%[cf]:%[cf]+1]\n\t" RELATE_WRITE_STATELESS_BODY
+               :
+               : [x] "v"(x), [cf] "n"(kCoefN), RELATE_WRITE_STATELESS_REGS
+               : "scc", "memory");
+}
+#undef RELATE_WRITE_STATELESS_HEAD
 #undef RELATE_WRITE_STATELESS_BODY
 #undef RELATE_WRITE_STATELESS_REGS
 
@@ -429,8 +483,10 @@ __device__ __forceinline__ void row_acc(double& c0, double& c1)
 
 // One site of the one-row recursion, state' = (state + rx) * (mismatch ? rho : 1), over the MPL words of
 // the wave; c0 + c1 = sum of the new states.  The first round of row `rp` is already on its way into
-// s[kBufA ..]; the first round of `rp_next` is requested after the last multiplication.
-template <int MPL>
+// s[kBufA ..]; the first round of `rp_next` is requested after the last multiplication (with REC, the site
+// record too: every scalar fetch of a site is then issued at one point, as far ahead of the next wait as the
+// registers allow).
+template <int MPL, int REC = 0>
 __device__ __forceinline__ void sweep_row(double& c0, double& c1, double rx, double rho, uint64_t sk, const uint64_t* rp,
                                           const uint64_t* rp_next)
 {
@@ -454,7 +510,12 @@ __device__ __forceinline__ void sweep_row(double& c0, double& c1, double rx, dou
     const uint64_t* rpl = rp;
     const uint64_t* rpn = rp_next;
     if constexpr (r + 1 < RR::NR) sload_round<RR::first(r + 1), RR::size(r + 1)>(rpl);
-    else sload_round<0, RR::size(0)>(rpn);
+    else {
+      sload_round<0, RR::size(0)>(rpn);
+      // REC: the record of the site after the next travels with the row words (1: forward list order, 2: backward)
+      if constexpr (REC == 1) prefetch_site<true>();
+      if constexpr (REC == 2) prefetch_site<false>();
+    }
     static_for<0, NC>([&](auto cc) __attribute__((always_inline)) {
       constexpr int c = decltype(cc)::value;
       row_acc<w0 + 4 * c, (nw - 4 * c < 4 ? nw - 4 * c : 4), r == 0 && c == 0>(c0, c1);
@@ -659,6 +720,110 @@ __device__ __forceinline__ double block_sum_hi(double (*red)[G], int& slot, uint
     return s;
   }
 }
+// Sum of a + b over the G > 1 waves of the workgroup, for the one-row loops.  After the last exchange step of the
+// wave sum the 16 lanes of row 3 hold it; one of them writes it to the wave's LDS entry (no read-out into
+// every lane), and after the barrier every wave adds the G entries in the same order.  Two sets of entries
+// alternate with the parity of the loop counter `step`, so that one barrier per call is enough (the caller
+// puts a barrier between the last use of the entries before its loop and the loop); which set is written is a
+// matter of which lane writes -- lane 63 holds the address of the wave's entry in set 0, lane 62 in set 1
+// (`wr_addr`, see exchange_addresses) -- and the reads of the two sets are two copies of the code with immediate
+// offsets behind a scalar branch: no vector instruction computes an address.  No scalar load may be in flight
+// after the wait before the barrier: the counted waits of the reads rely on LDS order.  The entries pass through
+// v[kX], v[kT] and v[kHi], which the wave sum has finished with.
+#define RELATE_XCHG_HEAD                                                                       \
+  "v_add_f64 v[%[x]:%[x]+1], %[a], %[b]\n\t"                                                   \
+  RELATE_DPP_STEP("quad_perm:[1,0,3,2]")                                                       \
+  RELATE_DPP_STEP("quad_perm:[2,3,0,1]")                                                       \
+  RELATE_DPP_STEP("row_half_mirror")                                                           \
+  RELATE_DPP_STEP("row_mirror")                                                                \
+  "s_nop 1\n\t"                                                                                \
+  "v_mov_b32_dpp v[%[t]], v[%[x]] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                 \
+  "v_mov_b32_dpp v[%[t]+1], v[%[x]+1] row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"             \
+  "s_mov_b32 exec_lo, 0xffff0000\n\t"                                                         \
+  "s_mov_b32 exec_hi, 0xffff0000\n\t"                                                         \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"                               \
+  "s_mov_b64 exec, -1\n\t"                                                                     \
+  "s_nop 0\n\t"                                                                                \
+  "v_mov_b32_dpp v[%[t]], v[%[x]] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                 \
+  "v_mov_b32_dpp v[%[t]+1], v[%[x]+1] row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"             \
+  "s_mov_b32 exec_lo, 0\n\t"                                                                   \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"                               \
+  "s_and_b32 vcc_lo, %[step], 1\n\t"                                                          \
+  "s_lshr_b32 exec_hi, 0x80000000, vcc_lo\n\t"                                                \
+  "ds_write_b64 %[wa], v[%[x]:%[x]+1]\n\t"                                                     \
+  "s_mov_b64 exec, -1\n\t"                                                                     \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                   \
+  "s_barrier\n\t"                                                                              \
+  "s_bitcmp0_b32 %[step], 0\n\t"                                                               \
+  "s_cbranch_scc0 .Lxs1%=\n\t"
+// the entries of one set: reads into v[kX], v[kT], v[kHi], the last one into the result register; ((e0 + e1) + e2) + e3
+#define RELATE_XCHG_SET2(o)                                                   \
+  "ds_read_b64 v[%[x]:%[x]+1], %[rb] offset:" #o "\n\t"                        \
+  "ds_read_b64 %[s], %[rb] offset:" #o "+8\n\t"                                \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                   \
+  "v_add_f64 %[s], v[%[x]:%[x]+1], %[s]\n\t"
+#define RELATE_XCHG_SET4(o)                                                   \
+  "ds_read_b64 v[%[x]:%[x]+1], %[rb] offset:" #o "\n\t"                        \
+  "ds_read_b64 v[%[t]:%[t]+1], %[rb] offset:" #o "+8\n\t"                      \
+  "ds_read_b64 v[%[h]:%[h]+1], %[rb] offset:" #o "+16\n\t"                     \
+  "ds_read_b64 %[s], %[rb] offset:" #o "+24\n\t"                               \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                   \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"               \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                   \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[h]:%[h]+1]\n\t"               \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                   \
+  "v_add_f64 %[s], v[%[x]:%[x]+1], %[s]\n\t"
+// eight entries: the first four as above into v[kX], then four more through v[kT], v[kHi] and the result register
+#define RELATE_XCHG_SET8(o)                                                   \
+  "ds_read_b64 v[%[x]:%[x]+1], %[rb] offset:" #o "\n\t"                        \
+  "ds_read_b64 v[%[t]:%[t]+1], %[rb] offset:" #o "+8\n\t"                      \
+  "ds_read_b64 v[%[h]:%[h]+1], %[rb] offset:" #o "+16\n\t"                     \
+  "ds_read_b64 %[s], %[rb] offset:" #o "+24\n\t"                               \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                   \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"               \
+  "ds_read_b64 v[%[t]:%[t]+1], %[rb] offset:" #o "+32\n\t"                     \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                   \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[h]:%[h]+1]\n\t"               \
+  "ds_read_b64 v[%[h]:%[h]+1], %[rb] offset:" #o "+40\n\t"                     \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                   \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], %[s]\n\t"                         \
+  "ds_read_b64 %[s], %[rb] offset:" #o "+48\n\t"                               \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                   \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"               \
+  "ds_read_b64 v[%[t]:%[t]+1], %[rb] offset:" #o "+56\n\t"                     \
+  "s_waitcnt lgkmcnt(2)\n\t"                                                   \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[h]:%[h]+1]\n\t"               \
+  "s_waitcnt lgkmcnt(1)\n\t"                                                   \
+  "v_add_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], %[s]\n\t"                         \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                   \
+  "v_add_f64 %[s], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"
+#define RELATE_XCHG_ASM(SET, o1)                                                                                      \
+  asm volatile(RELATE_XCHG_HEAD SET(0) "s_branch .Lxsd%=\n.Lxs1%=:\n\t" SET(o1) ".Lxsd%=:"                             \
+               : [s] "=&v"(s)                                                                                         \
+               : [a] "v"(a), [b] "v"(b), [wa] "v"(wr_addr), [rb] "v"(rd_base), [step] "s"(step), [x] "n"(kX), [t] "n"(kT), \
+                 [h] "n"(kHi)                                                                                         \
+               : "memory", "scc", "vcc")
+template <int G>
+__device__ __forceinline__ double exchange_sum(uint32_t wr_addr, uint32_t rd_base, int step, double a, double b)
+{
+  static_assert(G == 2 || G == 4 || G == 8, "waves per target");
+  double s;
+  if constexpr (G == 2) RELATE_XCHG_ASM(RELATE_XCHG_SET2, 16);
+  else if constexpr (G == 4) RELATE_XCHG_ASM(RELATE_XCHG_SET4, 32);
+  else RELATE_XCHG_ASM(RELATE_XCHG_SET8, 64);
+  return s;
+}
+// LDS addresses for exchange_sum: `red` = the 2 x G entries; lane 62 writes set 1, every other lane's address is
+// that of set 0 (only lane 63's is used).
+template <int G>
+__device__ __forceinline__ void exchange_addresses(double (*red)[G], uint32_t& wr_addr, uint32_t& rd_base)
+{
+  const int wv = threadIdx.x >> 6;
+  rd_base = (uint32_t)(uintptr_t)&red[0][0];
+  wr_addr = (uint32_t)(uintptr_t)&red[lane_id() == 62 ? 1 : 0][wv];
+  asm volatile("" : "+v"(wr_addr), "+v"(rd_base));  // stay in vector registers across the loop
+}
+
 template <int G, class... Parts>
 __device__ __forceinline__ double block_sum_regs(double (*red)[G], int& slot, Parts... parts)
 {
@@ -766,7 +931,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     const int w_ph = full_words > wbase ? full_words : wbase;
     set_stateless(sgpr64(self_here ? (1ull << kb) : 0ull), sgpr32(self_here ? 2u * (uint32_t)(kw - wbase) : 0u),
                   sgpr64((w_ph == full_words && rem) ? ~((1ull << rem) - 1ull) : ~0ull),
-                  sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL));
+                  sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL), 2u * MPL);
   };
 
   // bit of the target itself at the two forced sites; it is '1' at every other site of its list
@@ -848,26 +1013,47 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     double rho = ka.p.c.rho_theta;
     asm volatile("" : "+v"(rho));  // stays in a vector register: re-reading it from the argument segment would add a wait to every site
     double coef_j = sgpr_f64(rec[0].coef), nx_j = sgpr_f64(rec[0].nx);  // terms of the gap before site j
+    if constexpr (G > 1) set_site_terms(coef_j, nx_j);
     set_site_pointer(rec + 1);
     // nd >= 2: sites 0 and L-1 are always listed
     const uint64_t* rp = row_pointer(__builtin_amdgcn_readfirstlane(dk[1]), stride_bytes);
     const uint64_t* rp_next = row_pointer(__builtin_amdgcn_readfirstlane(dk[2 < nd ? 2 : nd - 1]), stride_bytes);
     sload_round<0, RowRounds<MPL>::size(0)>(rp);
+    uint32_t wr_addr = 0, rd_base = 0;
+    if constexpr (G > 1) {
+      exchange_addresses<G>(red, wr_addr, rd_base);
+      __syncthreads();  // every wave has read the entries of the sum above
+    }
     for (int left = nd - 2; left >= 0; left--) {
       if ((left & 31) == 0) rotate_priority(rank, left, 0);
-      const double rx = S * coef_j;
-      write_stateless<MPL, true>(S, coef_j);
-      // scalars of site j+1 travel during this sweep: the list entry two sites on and the terms of the gap before it
-      prefetch_site<true>();
-      const uint64_t skm = edge_mask(left, 0);
-      ls += nx_j;
-      double c0, c1;
-      sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
+      // scalars of site j+1 travel during this sweep: the list entry two sites on and the terms of the gap before
+      // it.  One wave per target: fetched before the sweep, copied into compiler registers after it.  Several: fetched
+      // with the next site's row words, after the last use of this site's (the wait before the barrier is then the
+      // only one of the site that finds a scalar fetch in flight), and used where they arrive.
+      double rx, c0, c1;
       uint32_t S_high;
-      S = block_sum_hi<G>(red, slot, S_high, c0, c1);
-      int s_next2;
-      fetched_site<true>(s_next2, coef_j, nx_j);  // arrived: the sweep has waited since the fetch
-      const uint64_t* rp_next2 = row_pointer(s_next2, stride_bytes);
+      const uint64_t* rp_next2;
+      if constexpr (G == 1) {
+        rx = S * coef_j;
+        write_stateless<MPL, true>(S, coef_j);
+        prefetch_site<true>();
+        const uint64_t skm = edge_mask(left, 0);
+        ls += nx_j;
+        sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
+        S = block_sum_hi<G>(red, slot, S_high, c0, c1);
+        int s_next2;
+        fetched_site<true>(s_next2, coef_j, nx_j);  // arrived: the sweep has waited since the fetch
+        rp_next2 = row_pointer(s_next2, stride_bytes);
+      } else {
+        rx = times_site_coef(S);
+        write_stateless_site<MPL>(S);
+        const uint64_t skm = edge_mask(left, 0);
+        add_site_nx(ls);
+        sweep_row<MPL, 1>(c0, c1, rx, rho, skm, rp, rp_next);
+        S = exchange_sum<G>(wr_addr, rd_base, left, c0, c1);
+        S_high = sgpr32((uint32_t)__double2hiint(S));
+        rp_next2 = fetched_row_pointer<true>(stride_bytes);
+      }
       if constexpr (kTouchRows) touch_row<MPL>(rp_next2, lane_bytes);
       if (!surely_in_range(S_high) && out_of_range_exact(S)) {
         const double inv = 1.0 / S;
@@ -933,25 +1119,42 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     double rho = ka.p.c.rho_theta;
     asm volatile("" : "+v"(rho));
     double coef_j = sgpr_f64(rec[nd - 1].coef), nx_j = sgpr_f64(rec[nd - 1].nx);  // terms used by the step to site j: index j + 1
+    if constexpr (G > 1) set_site_terms(coef_j, nx_j);
     set_site_pointer(rec + (nd - 2));
     const uint64_t* rp = row_pointer(__builtin_amdgcn_readfirstlane(dk[nd - 2]), stride_bytes);
     const uint64_t* rp_next = row_pointer(__builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]), stride_bytes);
     sload_round<0, RowRounds<MPL>::size(0)>(rp);
+    uint32_t wr_addr = 0, rd_base = 0;
+    if constexpr (G > 1) {
+      exchange_addresses<G>(red, wr_addr, rd_base);
+      __syncthreads();  // every wave has read the entries of the sum above
+    }
     for (int j = nd - 2; j >= 0; j--) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
-      const double rx = B * coef_j;
-      write_stateless<MPL, true>(B, coef_j);
-      // scalars of the step to site j-1 travel during this sweep
-      prefetch_site<false>();
-      const uint64_t skm = edge_mask(j, 0);
-      ls += nx_j;
-      double c0, c1;
-      sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
+      // scalars of the step to site j-1 travel during this sweep (see the forward loop)
+      double rx, c0, c1;
       uint32_t B_high;
-      B = block_sum_hi<G>(red, slot, B_high, c0, c1);
-      int s_prev2;
-      fetched_site<false>(s_prev2, coef_j, nx_j);
-      const uint64_t* rp_next2 = row_pointer(s_prev2, stride_bytes);
+      const uint64_t* rp_next2;
+      const uint64_t skm = edge_mask(j, 0);
+      if constexpr (G == 1) {
+        rx = B * coef_j;
+        write_stateless<MPL, true>(B, coef_j);
+        prefetch_site<false>();
+        ls += nx_j;
+        sweep_row<MPL>(c0, c1, rx, rho, skm, rp, rp_next);
+        B = block_sum_hi<G>(red, slot, B_high, c0, c1);
+        int s_prev2;
+        fetched_site<false>(s_prev2, coef_j, nx_j);
+        rp_next2 = row_pointer(s_prev2, stride_bytes);
+      } else {
+        rx = times_site_coef(B);
+        write_stateless_site<MPL>(B);
+        add_site_nx(ls);
+        sweep_row<MPL, 2>(c0, c1, rx, rho, skm, rp, rp_next);
+        B = exchange_sum<G>(wr_addr, rd_base, j, c0, c1);
+        B_high = sgpr32((uint32_t)__double2hiint(B));
+        rp_next2 = fetched_row_pointer<false>(stride_bytes);
+      }
       if constexpr (kTouchRows) touch_row<MPL>(rp_next2, lane_bytes);
       if (!surely_in_range(B_high) && out_of_range_exact(B)) {
         const double inv = 1.0 / B;

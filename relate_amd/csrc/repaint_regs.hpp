@@ -90,7 +90,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
     const int w_ph = full_words > wbase ? full_words : wbase;
     set_stateless(sgpr64(self_here ? (1ull << kb) : 0ull), sgpr32(self_here ? 2u * (uint32_t)(kw - wbase) : 0u),
                   sgpr64((w_ph == full_words && rem) ? ~((1ull << rem) - 1ull) : ~0ull),
-                  sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL));
+                  sgpr32(w_ph - wbase < MPL ? 2u * (uint32_t)(w_ph - wbase) : 2u * MPL), 2u * MPL);
   };
 
   const int s_first = __builtin_amdgcn_readfirstlane(dk[jb]);

@@ -2,7 +2,8 @@
 """Build-time check of the register-resident recursion kernels (relate_amd/csrc/paint_regs.hpp).
 
 The kernels keep their state and their row buffers and fixed scalars in registers addressed by number from inline
-asm (paint_regs.hpp: v48+ / s52+; paint_loop.hpp: v24+ / s24+), and rely on the compiler staying below those limits.  This script reads the device
+asm (paint_regs.hpp: v48+ / s52+ unless the kernel states other limits in a "relate_limits" comment; paint_loop.hpp:
+v24+ / s24+), and rely on the compiler staying below those limits.  This script reads the device
 assembly (hipcc -S --cuda-device-only) of the instantiation files and fails if any instruction the
 COMPILER emitted (i.e. outside the asm statements) inside a paint_kernel_r / repaint_kernel_r kernel names v48+ or s52+.
 
@@ -37,6 +38,10 @@ def check(path):
             continue
         if "#ASMEND" in line:
             in_asm = False
+            continue
+        lim = re.search(r"relate_limits v(\d+) s(\d+)", line)
+        if lim and in_asm:  # the kernel states its own limits (claim_registers)
+            v_limit, s_limit = int(lim.group(1)), int(lim.group(2))
             continue
         code = line.split(";")[0]
         if in_asm or not code.strip() or code.lstrip().startswith("."):

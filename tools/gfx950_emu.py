@@ -28,6 +28,19 @@ LDS_APERTURE_HI = 0x00010000      # high dword of flat addresses that fall into 
 SCRATCH_APERTURE_HI = 0x00020000  # ... into the private segment (src_private_base)
 
 
+def _const_expr(text):
+    """An assembler constant: a number (possibly negative), or sums and products of numbers (the assembler
+    evaluates such expressions)."""
+    text = text.strip()
+    try:
+        return int(text, 0)
+    except ValueError:
+        pass
+    if re.fullmatch(r"[0-9a-fA-FxX+* ]+", text) is None:
+        raise ValueError(f"not a constant expression: {text!r}")
+    return sum(int(np.prod([int(f, 0) for f in term.split("*")])) for term in text.split("+"))
+
+
 class EmuError(Exception):
     pass
 
@@ -1170,7 +1183,7 @@ class Wave:
         for t in tokens:
             for part in t.split():
                 if part.startswith("offset:"):
-                    off = int(part[7:], 0)
+                    off = _const_expr(part[7:])
         return off
 
     def _gaddr(self, vaddr, saddr, off, lane):
@@ -1366,6 +1379,23 @@ class Wave:
         out = np.zeros(64, dtype=np.uint32)
         for lane in range(64):
             sl = ((int(a[lane]) + off) >> 2) & 63
+            out[lane] = src[sl] if ex[sl] else 0
+        self.put32(d, out)
+
+    def op_ds_swizzle_b32(self, d, data, *m):
+        """lane permutation inside the LDS crossbar (no memory access).  offset[15] = 1: quad-permute mode, offset[7:0]
+        holds the source lane of each lane of a quad; offset[15] = 0: bit-mask mode inside groups of 32 lanes,
+        source lane = ((lane & and_mask) | or_mask) ^ xor_mask with the masks in offset[4:0], [9:5], [14:10].  A
+        source lane that is switched off delivers 0."""
+        ex = self.exec_mask()
+        off = self._mods((data,) + m)
+        src = self.vsrc32(data.split()[0])
+        out = np.zeros(64, dtype=np.uint32)
+        for lane in range(64):
+            if off & 0x8000:
+                sl = (lane & ~3) | ((off >> (2 * (lane & 3))) & 3)
+            else:
+                sl = (lane & 32) | ((((lane & 31) & (off & 31)) | ((off >> 5) & 31)) ^ ((off >> 10) & 31))
             out[lane] = src[sl] if ex[sl] else 0
         self.put32(d, out)
 
