@@ -270,13 +270,15 @@ __device__ __forceinline__ bool out_of_range(double S)
 // ahead pulls it back in time.  The data lands in v[kJunk], which nothing reads; loops that use this keep
 // their rescale thresholds out of v[kLo..kHi+1] (out_of_range_exact).
 constexpr int kJunk = kLo;
+constexpr int kLaneBytes = kLo + 1;  // 4 * lane, the address offset of those loads (set_touch_lane)
 constexpr bool kTouchRows = true;
+__device__ __forceinline__ void set_touch_lane(uint32_t lane_bytes) { asm volatile("v_mov_b32 v[%1], %0" ::"v"(lane_bytes), "n"(kLaneBytes)); }
 template <int MPL>
-__device__ __forceinline__ void touch_row(const uint64_t* p, uint32_t lane_bytes)
+__device__ __forceinline__ void touch_row(const uint64_t* p)
 {
-  asm volatile("global_load_dword v[%2], %1, %0" ::"s"(p), "v"(lane_bytes), "n"(kJunk) : "memory");
-  if constexpr (MPL > 32) asm volatile("global_load_dword v[%2], %1, %0 offset:256" ::"s"(p), "v"(lane_bytes), "n"(kJunk) : "memory");
-  if constexpr (MPL > 64) asm volatile("global_load_dword v[%2], %1, %0 offset:512" ::"s"(p), "v"(lane_bytes), "n"(kJunk) : "memory");
+  asm volatile("global_load_dword v[%1], v[%2], %0" ::"s"(p), "n"(kJunk), "n"(kLaneBytes) : "memory");
+  if constexpr (MPL > 32) asm volatile("global_load_dword v[%1], v[%2], %0 offset:256" ::"s"(p), "n"(kJunk), "n"(kLaneBytes) : "memory");
+  if constexpr (MPL > 64) asm volatile("global_load_dword v[%1], v[%2], %0 offset:512" ::"s"(p), "n"(kJunk), "n"(kLaneBytes) : "memory");
 }
 // A sum in [2^-33, 2^33) lies strictly inside the rescale thresholds (kRescaleLo = 1e-10 and its reciprocal):
 // one scalar compare on the high word settles nearly every site; the rest (NaN and negative values included)
@@ -1009,7 +1011,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     set_edge_mask(sk_last);
     uint32_t stride_bytes = 8u * (uint32_t)stride;
     asm volatile("" : "+s"(stride_bytes));  // not to be fetched again inside the loop: a scalar load there brings a wait with it
-    const uint32_t lane_bytes = 4u * (uint32_t)lane;
+    set_touch_lane(4u * (uint32_t)lane);
     double rho = ka.p.c.rho_theta;
     asm volatile("" : "+v"(rho));  // stays in a vector register: re-reading it from the argument segment would add a wait to every site
     double coef_j = sgpr_f64(rec[0].coef), nx_j = sgpr_f64(rec[0].nx);  // terms of the gap before site j
@@ -1054,7 +1056,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         S_high = sgpr32((uint32_t)__double2hiint(S));
         rp_next2 = fetched_row_pointer<true>(stride_bytes);
       }
-      if constexpr (kTouchRows) touch_row<MPL>(rp_next2, lane_bytes);
+      if constexpr (kTouchRows) touch_row<MPL>(rp_next2);
       if (!surely_in_range(S_high) && out_of_range_exact(S)) {
         const double inv = 1.0 / S;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
@@ -1115,7 +1117,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     set_edge_mask(sk_first);
     uint32_t stride_bytes = 8u * (uint32_t)stride;
     asm volatile("" : "+s"(stride_bytes));  // not to be fetched again inside the loop: a scalar load there brings a wait with it
-    const uint32_t lane_bytes = 4u * (uint32_t)lane;
+    set_touch_lane(4u * (uint32_t)lane);
     double rho = ka.p.c.rho_theta;
     asm volatile("" : "+v"(rho));
     double coef_j = sgpr_f64(rec[nd - 1].coef), nx_j = sgpr_f64(rec[nd - 1].nx);  // terms used by the step to site j: index j + 1
@@ -1155,7 +1157,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
         B_high = sgpr32((uint32_t)__double2hiint(B));
         rp_next2 = fetched_row_pointer<false>(stride_bytes);
       }
-      if constexpr (kTouchRows) touch_row<MPL>(rp_next2, lane_bytes);
+      if constexpr (kTouchRows) touch_row<MPL>(rp_next2);
       if (!surely_in_range(B_high) && out_of_range_exact(B)) {
         const double inv = 1.0 / B;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
@@ -1246,7 +1248,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     set_edge_mask(sk_first);
     uint32_t stride_bytes = 8u * (uint32_t)stride;
     asm volatile("" : "+s"(stride_bytes));
-    const uint32_t lane_bytes = 4u * (uint32_t)lane;
+    set_touch_lane(4u * (uint32_t)lane);
     // constants of the update in vector registers, opaque to the compiler: fetched again from the argument
     // segment inside the loop they would bring a wait with them
     double rho = ka.p.c.rho_theta;
@@ -1282,7 +1284,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       int s_prev2;
       fetched_site<false>(s_prev2, coef_j, nx_j);
       const uint64_t* rp_p2 = row_pointer(s_prev2, stride_bytes);
-      if constexpr (kTouchRows) touch_row<MPL>(rp_p2, lane_bytes);
+      if constexpr (kTouchRows) touch_row<MPL>(rp_p2);
       if (!surely_in_range(B_high) && out_of_range_exact(B)) {
         const double inv = 1.0 / B;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {

@@ -53,10 +53,13 @@ def test_two_theta_kernel_on_its_golden_chunk():
 
 
 @pytest.mark.parametrize("N,G,MPL,tp,td", [(600, 2, 8, 0.001, 0.001), (600, 4, 4, 0.001, 0.001), (1100, 1, 20, 0.001, 0.001),
-                                           (600, 2, 8, 0.001, 0.01), (4000, 8, 8, 0.001, 0.001)])
+                                           (600, 2, 8, 0.001, 0.01), (4000, 8, 8, 0.001, 0.001),
+                                           (5008, 4, 20, 0.001, 0.001), (5008, 2, 40, 0.001, 0.001)])
 def test_several_waves_and_several_rounds(N, G, MPL, tp, td):
-    """Workgroups of several waves (LDS exchange, barrier per site), lanes of more than 16 words (two rounds of row
-    words per site), one and two thetas, against the oracle; targets at both ends of the panel and across a word."""
+    """Workgroups of several waves (LDS exchange through lanes 63 / 62, barrier per site), lanes of more words than a
+    round of row words holds (two rounds per site), one and two thetas, the benchmark's 5008-haplotype geometry (4 x 20
+    words: one round) and its two-wave alternative, against the oracle; targets at both ends of the panel and across
+    a word."""
     import emu_kernel as ek
     seq, r, wb = sy.make_chunk(N=N, L=120, W=2, seed=N + G, r_mode="skew")
     for k0 in (0, 63, N - 2):
