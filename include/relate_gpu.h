@@ -118,7 +118,9 @@ int relate_plan_configure(relate_plan* p, int variant, int waves_per_target);
 
 /* Packs Data::sequence ('0'/'1' bytes, device pointer d_seq, L x N) into bit rows and their transpose
  * in HBM ("bit-planes"); replaces ReadSequenceFromBin's in-memory layout (src/data.cpp:541-550).
- * d_r: L doubles on the device (Data::r times rho).  wb: host array of num_windows+1 ints. */
+ * d_r: L doubles on the device (Data::r times rho).  wb: host array of num_windows+1 ints.
+ * d_seq is read by this call only; d_r is borrowed: relate_plan_prepare and relate_plan_repaint read it again, so
+ * the caller keeps it alive (and unchanged) until the plan loads another chunk or is destroyed. */
 int relate_plan_load_device(relate_plan* p, int N, int L, const void* d_seq, const void* d_r, int num_windows,
                             const int32_t* window_boundaries, void* stream);
 /* Same from host buffers (copies them to the device first). */

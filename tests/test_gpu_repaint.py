@@ -4,7 +4,8 @@ compared, target by target, with the CPU oracle fed with the same stones.
 
 Bar: row counts and zero pattern exact; floats (topology, logscales) within 1e-5 relative, and the
 log-probability log(topology) + logscale, which is what DistanceMeasure::GetMatrix consumes
-(src/anc_builder.cpp:122-141), within 1e-5 of its magnitude."""
+(src/anc_builder.cpp:122-141), within 1e-5 of its magnitude.  Asserted on top of that, because it is what was
+measured: no topology float differs from the oracle's in any bit."""
 import numpy as np
 import pytest
 
@@ -14,6 +15,20 @@ import synth_np as sy
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-5
+# Share of re-painted floats whose last bit may differ from the oracle's.  The bar is REL_TOL; what is asserted is what
+# was measured on every case here and on the benchmark's windows (gpurun_out/repaint_bit_identity.txt): none.
+MAX_SHARE_NOT_IDENTICAL = 0.0
+
+
+def _record(line):
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "repaint_bit_identity.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
 
 
 def _ra():
@@ -93,7 +108,8 @@ def test_repaint_matches_oracle(N, L, W, seed, mode, theta, waves):
         top, ls, off, pitch = res[w]
         targets = None if N <= 130 else list(range(0, N, 7)) + [N - 1]
         frac = check_window(seq, r, theta, host_stones, w, top, ls, off, pitch, targets)
-        assert frac < 1e-4, f"{frac:.2e} of the floats are not bit-identical to the oracle"
+        _record(f"re-painting N={N} L={L} seed={seed} waves={waves} window {w}: share of floats not bit-identical {frac:.3e}")
+        assert frac <= MAX_SHARE_NOT_IDENTICAL, f"{frac:.2e} of the floats are not bit-identical to the oracle"
 
 
 def test_repaint_known_answer_toy():
