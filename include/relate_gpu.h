@@ -46,7 +46,9 @@ size_t relate_record_bytes(int N);
  * theta == NULL keeps Data's default 0.001 (src/data.cpp:97); rho == NULL
  * leaves r unscaled.  device < 0 shards the targets over every visible device
  * (ranges of equal numbers of derived sites; the first device packs the matrix,
- * the others receive the packed copy from it).  The files appear complete or
+ * the others receive the packed copy from it), or over the devices listed in the
+ * environment variable RELATE_DEVICES ("0,2,3"; an index may repeat: "0,0" runs
+ * two plans with a host thread each on one GPU).  The files appear complete or
  * not at all: records are written to relate_<w>.bin.part and renamed when every
  * window is complete; on failure no relate_<w>.bin of this chunk is left.
  * ------------------------------------------------------------------------ */

@@ -1624,10 +1624,25 @@ int relate_paint_chunk(const char* output_dir, int chunk_index, const double* th
   if (int rc = files.open_all(paint_dir, W)) return rc;
 
   // contiguous target ranges, one per device; every record has a fixed place k*R in its file
+  // device < 0: all visible devices, or the list in RELATE_DEVICES ("0,2,3"; an index may repeat, "0,0" runs two
+  // plans, two host threads and the device-to-device hand-over on one GPU)
   std::vector<int> devs;
-  if (device >= 0) devs.push_back(device);
-  else
+  if (device >= 0) {
+    devs.push_back(device);
+  } else if (const char* list = getenv("RELATE_DEVICES"); list && *list) {
+    for (const char* q = list; *q;) {
+      char* end = nullptr;
+      const long v = strtol(q, &end, 10);
+      if (end == q || v < 0 || v >= ndev_all || (*end && *end != ','))
+        return fail(RELATE_EINVAL, std::string("RELATE_DEVICES: expected device indices below ") + std::to_string(ndev_all) +
+                                       " separated by commas, got \"" + list + "\"");
+      devs.push_back((int)v);
+      q = *end ? end + 1 : end;
+    }
+    if (devs.empty() || devs.size() > 64) return fail(RELATE_EINVAL, "RELATE_DEVICES names no device or more than 64");
+  } else {
     for (int i = 0; i < ndev_all; i++) devs.push_back(i);
+  }
   const int nd = (int)std::min<size_t>(devs.size(), (size_t)N);
   // the first device packs; the others receive the packed matrix from it
   relate_plan* first = nullptr;

@@ -101,3 +101,34 @@ def test_paint_to_files_of_a_shard_and_staging_release(tmp_path):
         raw = np.fromfile(tmp_path / f"relate_{w}.bin", dtype=np.uint8)
         assert raw.size == N * R
         assert compare_records(raw.reshape(1, N, R), want[w:w + 1], N, f"shards, window {w}") == 0.0
+
+
+def test_several_plans_share_one_chunk(tmp_path, monkeypatch):
+    """relate_paint_chunk(device < 0), the in-process multi-device host: one plan and one host thread per entry of the
+    device list, the packed matrix handed from the first plan to the others device to device, target ranges of equal
+    work, every thread writing its records at k*R of the same files.  With one GPU the list names it several times
+    (RELATE_DEVICES=0,0,0): everything but the second card runs.  Files byte-identical to the one-device run's."""
+    import relate_amd as ra
+    N, W = 333, 4
+    seq, r, wb = sy.make_chunk(N=N, L=1800, W=W, seed=44, r_mode="skew")
+    one, many = tmp_path / "one", tmp_path / "many"
+    for d in (one, many):
+        d.mkdir()
+        ra.write_chunk(d, 0, seq, r, wb)
+    ra.paint_chunk(one, 0, 0.001, 1.0, device=0)
+    monkeypatch.setenv("RELATE_DEVICES", "0,0,0")
+    ra.paint_chunk(many, 0, 0.001, 1.0, device=-1)
+    R = ra.record_bytes(N)
+    assert sorted(os.listdir(many / "chunk_0" / "paint")) == [f"relate_{w}.bin" for w in range(W)]
+    for w in range(W):
+        a = np.fromfile(one / "chunk_0" / "paint" / f"relate_{w}.bin", dtype=np.uint8)
+        b = np.fromfile(many / "chunk_0" / "paint" / f"relate_{w}.bin", dtype=np.uint8)
+        assert a.size == N * R and np.array_equal(a, b), f"window {w}"
+    want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb)
+    got = np.stack([np.fromfile(many / "chunk_0" / "paint" / f"relate_{w}.bin", dtype=np.uint8).reshape(N, R) for w in range(W)])
+    assert np.array_equal(ol.decode_records(got)["a_snp"], ol.decode_records(want)["a_snp"])
+    # a list that names a device the machine does not have is refused (the files of the run above stay as they are)
+    monkeypatch.setenv("RELATE_DEVICES", "0,99")
+    with pytest.raises(ra.RelateError) as e:
+        ra.paint_chunk(many, 0, 0.001, 1.0, device=-1)
+    assert e.value.code == -1 and "RELATE_DEVICES" in str(e.value)
