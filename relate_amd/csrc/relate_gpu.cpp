@@ -1172,6 +1172,9 @@ int copy_back_threads()
 // The records come back window by window through a ring of pinned slots, and a few host threads hand each
 // window's slab to the sink as soon as it has arrived: the sink (a memcpy into pageable memory, or pwrite) is
 // slower than the link, and the slabs of different windows go to different places.
+// With several batches of targets the copy-back of a batch runs beside the painting of the next one: two record
+// buffers in HBM, the copies on a stream of their own behind an event of the painting stream, and a host thread
+// per batch that feeds the ring while the calling thread prepares and paints the next batch.
 template <class Sink>
 int paint_range(relate_plan* p, double theta_p, double theta_d, int k_begin, int k_end, Sink&& sink)
 {
@@ -1182,54 +1185,73 @@ int paint_range(relate_plan* p, double theta_p, double theta_d, int k_begin, int
   if (int rc = derived_counts(p, k_begin, k_end, nd)) return rc;
   size_t free_b = 0, total_b = 0;
   HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-  size_t budget = std::min<size_t>(free_b / 2, (size_t)24 << 30);
   const size_t slab_cap = std::max(kStagingBytes / 2, R);  // two slots at least (one target per slot at worst)
   int rc = RELATE_OK;
-  DevBuf d_out;
+  DevBuf d_out[2];
   std::vector<int> cuts;
-  // a refused allocation halves the budget and plans the batches again
+  int widest = 0, n_buf = 1;
+  // batches of at most 12 GiB of records and lists (a quarter of the free memory at most), two of them resident: the
+  // link carries a batch in a fifth of a second, during which the next one is painted, so that only the painting of
+  // the first batch is not hidden.  A refused allocation halves the budget and plans the batches again.
+  size_t budget = std::min<size_t>(free_b / 4, (size_t)12 << 30);
+  if (const char* e = std::getenv("RELATE_BATCH_BYTES")) {  // tests: several batches of a small chunk
+    const long long v = std::atoll(e);
+    if (v > 0) budget = std::min<size_t>(budget, (size_t)v);
+  }
   for (int attempt = 0;; attempt++) {
     cuts = plan_batches(nd, k_begin, R, W, budget, slab_cap);
-    int widest = 0;
+    n_buf = cuts.size() > 2 ? 2 : 1;
+    widest = 0;
     for (size_t b = 0; b + 1 < cuts.size(); b++) widest = std::max(widest, cuts[b + 1] - cuts[b]);
-    rc = d_out.reserve(R * (size_t)W * (size_t)widest);
+    rc = RELATE_OK;
+    for (int i = 0; i < n_buf && rc == RELATE_OK; i++) rc = d_out[i].reserve(R * (size_t)W * (size_t)widest);
     if (rc == RELATE_OK || attempt == 6 || widest == 1) break;
+    d_out[0].release();
+    d_out[1].release();
     budget /= 2;
   }
   if (rc) return rc;
-  int widest = 0;
-  for (size_t b = 0; b + 1 < cuts.size(); b++) widest = std::max(widest, cuts[b + 1] - cuts[b]);
   const size_t slot_bytes = R * (size_t)widest;
   const int n_slots = (int)std::max<size_t>(2, std::min<size_t>((size_t)W, std::max<size_t>(kStagingBytes, 2 * slot_bytes) / slot_bytes));
   PinnedLease lease;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t painted[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> arrived(n_slots, nullptr);
+  auto cleanup = [&]() {
+    for (auto& e : arrived)
+      if (e) (void)hipEventDestroy(e);
+    for (auto& e : painted)
+      if (e) (void)hipEventDestroy(e);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    d_out[0].release();
+    d_out[1].release();
+  };
   if (int rc2 = lease.acquire(slot_bytes * (size_t)n_slots)) {
-    d_out.release();
+    cleanup();
     return rc2;
   }
   uint8_t* h_ring = static_cast<uint8_t*>(lease.p);
-  std::vector<hipEvent_t> arrived(n_slots, nullptr);
-  for (int i = 0; i < n_slots; i++) {
-    hipError_t e = hipEventCreateWithFlags(&arrived[i], hipEventDisableTiming);
+  {
+    hipError_t e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&painted[i], hipEventDisableTiming);
+    for (int i = 0; i < n_slots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&arrived[i], hipEventDisableTiming);
     if (e != hipSuccess) {
-      for (int v = 0; v < i; v++) (void)hipEventDestroy(arrived[v]);
-      d_out.release();
-      return fail(RELATE_EGPU, std::string("hipEventCreate: ") + hipGetErrorString(e));
+      cleanup();
+      return fail(RELATE_EGPU, std::string("stream / event creation: ") + hipGetErrorString(e));
     }
   }
   const int n_threads = std::min(copy_back_threads(), std::min(W, n_slots));
-  for (size_t b = 0; b + 1 < cuts.size() && rc == RELATE_OK; b++) {
-    const int k0 = cuts[b], k1 = cuts[b + 1], nk = k1 - k0;
-    rc = relate_plan_prepare(p, theta_p, theta_d, k0, k1, nullptr, p->own_stream);
-    if (rc == RELATE_ENOMEM && nk > 1) {
-      // the site lists did not fit beside the records: split this batch
-      cuts.insert(cuts.begin() + (long)b + 1, k0 + nk / 2);
-      rc = RELATE_OK;
-      b--;
-      continue;
+
+  // The copy-back of one painted batch: the windows through the ring on copy_stream, drained by n_threads host
+  // threads.  Runs on a thread of its own; its result and message are left in `crc` / `cerr`.
+  int crc = RELATE_OK;
+  std::string cerr;
+  auto copy_back = [&](int k0, int nk, const uint8_t* d_records, hipEvent_t ready) {
+    if (hipSetDevice(p->device) != hipSuccess || hipStreamWaitEvent(copy_stream, ready, 0) != hipSuccess) {
+      crc = RELATE_EGPU;
+      cerr = "copy-back could not be ordered behind the painting";
+      return;
     }
-    if (rc) break;
-    rc = relate_plan_paint(p, d_out.p, p->own_stream);
-    if (rc) break;
     const size_t slab = R * (size_t)nk;
     // window w travels through slot w % n_slots: issued[w] once its copy is on the stream, drained[w] once the
     // sink has returned (the slot may then take window w + n_slots)
@@ -1283,24 +1305,67 @@ int paint_range(relate_plan* p, double theta_p, double theta_d, int k_begin, int
         cv.wait(lk, [&] { return drained[w - n_slots] || failed; });
         if (failed) break;
       }
-      e = hipMemcpyAsync(h_ring + (size_t)slot * slot_bytes, static_cast<const uint8_t*>(d_out.p) + (size_t)w * slab, slab,
-                         hipMemcpyDeviceToHost, p->own_stream);
-      if (e == hipSuccess) e = hipEventRecord(arrived[slot], p->own_stream);
+      e = hipMemcpyAsync(h_ring + (size_t)slot * slot_bytes, d_records + (size_t)w * slab, slab, hipMemcpyDeviceToHost, copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(arrived[slot], copy_stream);
       std::lock_guard<std::mutex> lk(m);
       if (e == hipSuccess) issued[w] = 1;
       else failed = true;
       cv.notify_all();
     }
     for (auto& t : th) t.join();
-    // the ring and the device buffer are reused by the next batch: everything must have left the stream
-    const hipError_t es = hipStreamSynchronize(p->own_stream);
-    if (e != hipSuccess) rc = fail(RELATE_EGPU, std::string("copy-back failed: ") + hipGetErrorString(e));
+    // the ring and the record buffer are reused: everything must have left the stream
+    const hipError_t es = hipStreamSynchronize(copy_stream);
+    if (e != hipSuccess) {
+      crc = RELATE_EGPU;
+      cerr = std::string("copy-back failed: ") + hipGetErrorString(e);
+    }
     for (int ti = 0; ti < n_threads; ti++)
-      if (rcs[ti] != RELATE_OK && rc == RELATE_OK) rc = fail(rcs[ti], errs[ti]);
-    if (es != hipSuccess && rc == RELATE_OK) rc = fail(RELATE_EGPU, std::string("painting or copy-back failed: ") + hipGetErrorString(es));
+      if (rcs[ti] != RELATE_OK && crc == RELATE_OK) {
+        crc = rcs[ti];
+        cerr = errs[ti];
+      }
+    if (es != hipSuccess && crc == RELATE_OK) {
+      crc = RELATE_EGPU;
+      cerr = std::string("painting or copy-back failed: ") + hipGetErrorString(es);
+    }
+  };
+
+  std::thread copier;
+  auto join_copier = [&]() {
+    if (copier.joinable()) copier.join();
+    if (crc != RELATE_OK && rc == RELATE_OK) rc = fail(crc, cerr);
+  };
+  for (size_t b = 0; b + 1 < cuts.size() && rc == RELATE_OK; b++) {
+    const int k0 = cuts[b], k1 = cuts[b + 1], nk = k1 - k0;
+    const int buf = n_buf == 2 ? (int)(b & 1) : 0;
+    // the copy-back of batch b-1 (the other buffer) may still run; that of batch b-2 (this buffer) has been joined
+    rc = relate_plan_prepare(p, theta_p, theta_d, k0, k1, nullptr, p->own_stream);
+    if (rc == RELATE_ENOMEM && nk > 1) {
+      // the site lists did not fit beside the records: split this batch (the buffers are wide enough for a part)
+      cuts.insert(cuts.begin() + (long)b + 1, k0 + nk / 2);
+      if (n_buf == 1) {  // a second batch after all: it reuses the one buffer, after the copy-back of the first
+        join_copier();
+      }
+      rc = RELATE_OK;
+      b--;
+      continue;
+    }
+    if (rc) break;
+    if (n_buf == 1) join_copier();  // one buffer: the previous batch must have left it
+    if (rc) break;
+    rc = relate_plan_paint(p, d_out[buf].p, p->own_stream);
+    if (rc) break;
+    if (hipEventRecord(painted[buf], p->own_stream) != hipSuccess) {
+      rc = fail(RELATE_EGPU, "hipEventRecord failed");
+      break;
+    }
+    join_copier();  // the ring serves one batch at a time
+    if (rc) break;
+    copier = std::thread(copy_back, k0, nk, static_cast<const uint8_t*>(d_out[buf].p), painted[buf]);
   }
-  for (int i = 0; i < n_slots; i++) (void)hipEventDestroy(arrived[i]);
-  d_out.release();
+  join_copier();
+  (void)hipStreamSynchronize(p->own_stream);
+  cleanup();
   return rc;
 }
 

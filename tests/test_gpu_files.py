@@ -132,3 +132,20 @@ def test_several_plans_share_one_chunk(tmp_path, monkeypatch):
     with pytest.raises(ra.RelateError) as e:
         ra.paint_chunk(many, 0, 0.001, 1.0, device=-1)
     assert e.value.code == -1 and "RELATE_DEVICES" in str(e.value)
+
+
+def test_batches_of_targets_through_two_record_buffers(monkeypatch):
+    """relate_paint_stones with the targets in many batches (RELATE_BATCH_BYTES shrinks them): each batch's records are
+    copied back while the next batch is painted into the other buffer; every record against the oracle."""
+    import relate_amd as ra
+    from test_gpu_parity import compare_records
+    N, W = 200, 6
+    seq, r, wb = sy.make_chunk(N=N, L=3000, W=W, seed=45, r_mode="flat")
+    R = ra.record_bytes(N)
+    monkeypatch.setenv("RELATE_BATCH_BYTES", str(23 * (W * R + 28 * 400)))  # about twenty targets per batch
+    got = ra.paint_stones(seq, r, 0.001, 0.001, wb, device=0)
+    want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb)
+    assert compare_records(got, want, N, "nine batches") == 0.0
+    got = ra.paint_stones(seq, r, 0.001, 0.01, wb, device=0, k_begin=37, k_end=171)
+    want = ol.oracle().paint_stones(seq, r, 0.001, 0.01, wb, 37, 171)
+    assert compare_records(got, want, N, "a range in batches, two thetas") == 0.0
