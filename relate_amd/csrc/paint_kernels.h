@@ -123,7 +123,8 @@ struct RepaintLaunch {
   const int64_t* row_off;   // [K] first row of each target
   const double* last_coef;  // [K]
   const double* last_nx;
-  double* scratch;          // [rows][pitch]
+  double* scratch;          // [repaint_checkpoint_rows(rows, K, MPL)][pitch] alpha checkpoints
+  double* cp_sum;           // one double per checkpoint row
   float* topology;          // [rows][pitch]
   float* logscales;         // [rows]
   int w, pitch;
@@ -131,5 +132,15 @@ struct RepaintLaunch {
   PaintConsts c;
 };
 hipError_t launch_repaint(const RepaintLaunch& a, PaintGeometry g, hipStream_t st);
+// Rows of a section that the re-painting walks between two alpha checkpoints: the backward launch keeps B - 1 alpha
+// rows and the beta row in accumulation registers, 2 * MPL of them each, in what 256 registers per lane leave beside
+// the kernel's 56 + 2 * MPL and the compiler's 32 AGPRs; at most 8.  1: every row is a checkpoint.
+constexpr int repaint_block_rows(int MPL)
+{
+  const int slots = (256 - 32 - (56 + 2 * MPL)) / (2 * MPL);
+  return slots < 2 ? 1 : (slots > 8 ? 8 : slots);
+}
+// Checkpoint rows of a window of `rows` topology rows over K targets: target t's start at row_off[t] / B + t.
+constexpr long long repaint_checkpoint_rows(long long rows, int K, int MPL) { return rows / repaint_block_rows(MPL) + K + 1; }
 
 }  // namespace relate

@@ -184,7 +184,7 @@ struct relate_plan {
   bool stones_on_host = false;
   hipStream_t prepare_stream = nullptr;  // the null stream is a stream like any other: validity is a flag of its own
   bool have_prepare_stream = false;
-  DevBuf row_off, last_coef, last_nx, scratch;
+  DevBuf row_off, last_coef, last_nx, scratch, cp_sum;
   DevBuf dm_args;  // per-row arguments of the distance-matrix kernel
   DevBuf mm_min, mm_counts, mm_off, mm_ci, mm_cj, mm_cd;  // MinMatch scans: row minima, pair counts / offsets, the pairs
   HostBuf h_mm;
@@ -651,7 +651,9 @@ int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* 
   if (int rc = p->row_off.reserve(sizeof(int64_t) * (size_t)K)) return rc;
   if (int rc = p->last_coef.reserve(sizeof(double) * (size_t)K)) return rc;
   if (int rc = p->last_nx.reserve(sizeof(double) * (size_t)K)) return rc;
-  if (int rc = p->scratch.reserve(sizeof(double) * (size_t)rows * pitch)) return rc;
+  const size_t cp_rows = (size_t)relate::repaint_checkpoint_rows(rows, K, p->geo_repaint.MPL);
+  if (int rc = p->scratch.reserve(sizeof(double) * cp_rows * pitch)) return rc;
+  if (int rc = p->cp_sum.reserve(sizeof(double) * cp_rows)) return rc;
   HIP_TRY(hipMemcpyAsync(p->row_off.p, ro, sizeof(int64_t) * (size_t)K, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(p->staged, st));
   p->stage_in_flight = true;
@@ -673,6 +675,7 @@ int relate_plan_repaint(relate_plan* p, int window, const void* d_stones, void* 
   a.last_coef = p->last_coef.as<double>();
   a.last_nx = p->last_nx.as<double>();
   a.scratch = p->scratch.as<double>();
+  a.cp_sum = p->cp_sum.as<double>();
   a.topology = static_cast<float*>(d_topology);
   a.logscales = static_cast<float*>(d_logscales);
   a.w = window;

@@ -4,11 +4,18 @@
 // alpha stone at its first site and the beta stone at its last, and the product alpha * beta of every site
 // of the section is written as a row of the `topology` matrix (float), with its logscale.
 //
-// Two launches per window.  The forward launch keeps every alpha row (double, :786-919 keeps them in
-// `alpha[j]`) in a scratch matrix in HBM; the backward launch reads them back while it walks the section
-// in the other direction and writes float(alpha[j][n] * beta[j][n]) (:958-969,:1067-1078), taken before the
-// beta row is rescaled (:1081-1095).  Rows have a pitch of G*MPL*64 elements (>= N), so the lanes past N
-// and the target's own lane, which hold exact zeros, are stored like any other.
+// Two launches per window.  The reference keeps every alpha row of a section (double, :786-919) until the
+// backward pass has multiplied it into beta (:958-969,:1067-1078, before the beta row is rescaled, :1081-1095).
+// Here the forward launch keeps every B-th alpha row (a checkpoint, with the sum that goes with it) in a scratch
+// matrix in HBM; the backward launch walks the section in blocks of B rows from its end: it parks beta in
+// accumulation registers (AGPRs), loads the block's checkpoint, runs the forward recursion again over the block
+// -- the same instructions as the forward launch, hence the same doubles -- parking each alpha row in AGPRs too,
+// takes beta back and walks the block downwards, multiplying.  Per element of the topology that is 16/B bytes of
+// checkpoint traffic beside the 4 bytes of the result, instead of 16.  B follows from the registers: the AGPR
+// slots (2*MPL registers each, B - 1 alpha rows and beta) are what 256 registers per lane (two waves per SIMD) leave
+// beside the kernel's own and the compiler's AGPRs, at most 8 rows; from 32 words per lane on there is room for one
+// slot only and every row is a checkpoint (B = 1: the reference's scheme).  Rows have a pitch of G*MPL*64 elements (>= N), so the lanes past N and the
+// target's own lane, which hold exact zeros, are stored like any other.
 //
 // Internal header; instantiated per G by paint_regs_g*.hip.
 #pragma once
@@ -16,6 +23,71 @@
 
 namespace relate {
 namespace regs {
+
+constexpr int repaint_block(int MPL) { return repaint_block_rows(MPL); }  // paint_kernels.h: the host sizes the scratch with it
+
+// A kernel whose asm names AGPRs shares its register budget with them: the backward kernel is compiled with
+// amdgpu_num_vgpr(32), which gives the compiler v0..v31 and a0..a31 (it parks spilled values there); the slots
+// start at a32, and slots, compiler AGPRs and the 56 + 2*MPL registers of the kernel stay inside 256 per lane: two
+// waves per SIMD (at one, the launch is bound by the latency of its dependent chains).  Every AGPR the asm names must be on a clobber list (the back end sizes the
+// register file from them), and tools/check_regs.py reads the "relate_limits a32" left in the assembly and fails
+// the build if a compiler instruction names an AGPR from a32 on (or, as everywhere, a VGPR from v48 on).
+constexpr int kSlot0 = 32;
+#define RELATE_BWD_REPAINT_ATTR __attribute__((amdgpu_num_vgpr(32), amdgpu_num_sgpr(RELATE_CS_ATTR)))
+#define RELATE_ACLOB_64 "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95"
+#define RELATE_ACLOB_96 RELATE_ACLOB_64, "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+#define RELATE_ACLOB_112 RELATE_ACLOB_96, "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143"
+#define RELATE_ACLOB_120 RELATE_ACLOB_112, "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151"
+#define RELATE_ACLOB_128 RELATE_ACLOB_120, "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159"
+#define RELATE_ACLOB_144 RELATE_ACLOB_128, "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175"
+template <int MPL>
+__device__ __forceinline__ void claim_slots()
+{
+  constexpr int n = repaint_block(MPL) > 1 ? 2 * MPL * repaint_block(MPL) : 0;
+  static_assert(kSlot0 + n <= 256 && kA0 + 2 * MPL + kSlot0 + n <= 256, "registers of two waves per SIMD");
+  // no slots (every row a checkpoint): one AGPR is named all the same, so that the register budget of the kernel is
+  // split the same way for every instantiation (without any AGPR the back end hands all of it to the compiler as VGPRs)
+  if constexpr (n == 0) asm volatile("; relate_limits a%0" ::"n"(kSlot0) : "a32");
+  if constexpr (n == 64) asm volatile("; relate_limits a%0" ::"n"(kSlot0) : RELATE_ACLOB_64);
+  if constexpr (n == 96) asm volatile("; relate_limits a%0" ::"n"(kSlot0) : RELATE_ACLOB_96);
+  if constexpr (n == 112) asm volatile("; relate_limits a%0" ::"n"(kSlot0) : RELATE_ACLOB_112);
+  if constexpr (n == 120) asm volatile("; relate_limits a%0" ::"n"(kSlot0) : RELATE_ACLOB_120);
+  if constexpr (n == 128) asm volatile("; relate_limits a%0" ::"n"(kSlot0) : RELATE_ACLOB_128);
+  if constexpr (n == 144) asm volatile("; relate_limits a%0" ::"n"(kSlot0) : RELATE_ACLOB_144);
+  static_assert(n == 0 || n == 64 || n == 96 || n == 112 || n == 120 || n == 128 || n == 144, "an AGPR clobber list for every block size");
+}
+// state block <-> AGPR slot S (registers a[kSlot0 + S*2*MPL .. kSlot0 + (S+1)*2*MPL))
+template <int S, int MPL>
+__device__ __forceinline__ void slot_save()
+{
+  static_for<0, 2 * MPL>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    asm volatile("v_accvgpr_write_b32 a[%0], v[%1]" ::"n"(kSlot0 + S * 2 * MPL + i), "n"(kA0 + i));
+  });
+}
+template <int S, int MPL>
+__device__ __forceinline__ void slot_load()
+{
+  asm volatile("s_nop 1");
+  static_for<0, 2 * MPL>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    asm volatile("v_accvgpr_read_b32 v[%1], a[%0]" ::"n"(kSlot0 + S * 2 * MPL + i), "n"(kA0 + i));
+  });
+}
+// float(word I of slot S * state word I)
+template <int S, int I, int MPL>
+__device__ __forceinline__ float slot_times_state()
+{
+  float f;
+  asm volatile(
+      "v_accvgpr_read_b32 v[%[t]], a[%[a]]\n\t"
+      "v_accvgpr_read_b32 v[%[t]+1], a[%[a]+1]\n\t"
+      "v_mul_f64 v[%[t]:%[t]+1], v[%[t]:%[t]+1], v[%[s]:%[s]+1]\n\t"
+      "v_cvt_f32_f64 %[f], v[%[t]:%[t]+1]"
+      : [f] "=v"(f)
+      : [a] "n"(kSlot0 + S * 2 * MPL + 2 * I), [t] "n"(kT), [s] "n"(kA0 + 2 * I));
+  return f;
+}
 
 struct RepaintKArgs {
   const uint64_t* rows;
@@ -30,7 +102,8 @@ struct RepaintKArgs {
   const int64_t* row_off;   // [K] first row of target t in scratch / topology / logscales
   const double* last_coef;  // [K] gap terms of the section's last site: r[last] alone (:737-750)
   const double* last_nx;
-  double* scratch;          // [rows][pitch] alpha rows
+  double* scratch;          // [rows / B + K + 1][pitch] alpha checkpoints: row j of target t at row_off[t] / B + t + j / B
+  double* cp_sum;           // the sum of each checkpoint row as the forward recursion holds it (1 after a rescale)
   float* topology;          // [rows][pitch]
   float* logscales;         // [rows]
   int w, pitch;
@@ -53,8 +126,31 @@ __device__ __forceinline__ double state_get()
   return v;
 }
 
+// The same with the slot chosen at run time (a wave-uniform index below NS): the sweeps around these calls then
+// exist once in the code instead of once per row of a block, which keeps the kernel inside the instruction cache.
+template <int MPL, int NS>
+__device__ __forceinline__ void slot_save_at(int s)
+{
+  static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
+    if (s == decltype(sc)::value) slot_save<decltype(sc)::value, MPL>();
+  });
+}
+// row `tr` (this lane's column, words 64 floats apart) = float(slot s * state block)
+template <int MPL, int NS>
+__device__ __forceinline__ void slot_product_at(int s, GlobalFloat* __restrict__ tr)
+{
+  static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
+    if (s == decltype(sc)::value) {
+      static_for<0, MPL>([&](auto wc) __attribute__((always_inline)) {
+        constexpr int wd = decltype(wc)::value;
+        tr[(size_t)wd * 64] = slot_times_state<decltype(sc)::value, wd, MPL>();
+      });
+    }
+  });
+}
+
 template <int MPL, int G, bool BWD>
-__global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(const RepaintKArgs ka)
+__device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
 {
   static_assert(MPL >= 4 && MPL <= kMaxMPL, "states per lane");
   extern __shared__ double lds_dyn[];
@@ -80,7 +176,7 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
   const uint64_t* rows_w = ka.rows + wbase;
   const size_t R = 56 + (size_t)8 * N;
   const uint8_t* stone = ka.stones + (size_t)t * R;
-  const size_t row0 = (size_t)ka.row_off[t];
+  const size_t row0 = (size_t)sgpr64((uint64_t)ka.row_off[t]);  // uniform, and wanted in scalar registers below
   const size_t pitch = (size_t)ka.pitch;
   const size_t col = (size_t)wbase * 64 + lane;
 
@@ -100,12 +196,46 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
   const uint64_t sk_last = sgpr64(((ka.rows[(size_t)s_last * stride + kw] >> kb) & 1ull) ? ~0ull : 0ull);
   const double rho = ka.p.c.rho_theta;
 
+  constexpr int B = repaint_block(MPL);
+  const size_t cp0 = row0 / (size_t)B + (size_t)t;  // first checkpoint row of this target
+  // One site of the forward recursion (:829-919) on the state block, shared by the forward launch and by the
+  // backward launch's second run over a block: the same instructions in the same order, so that both produce the
+  // same doubles.  Returns true when the row was rescaled (lg = log of the sum it was divided by).
+  // Scalars that travel: coef_j (gap before this site), the running record pointer, s_next (site after this one).
+  auto forward_site = [&](int j, double& S, double& coef_j, double& nx_j, const uint64_t*& rp, int& s_next, double rho_l,
+                          int stride_l, double& lg) __attribute__((always_inline)) -> bool {
+    const double rx = S * coef_j;
+    write_stateless<MPL, false>(S, coef_j);
+    prefetch_site<true>();
+    const uint64_t skm = edge_select(j, nds - 1, sk_last);
+    double c0, c1;
+    const uint64_t* rp_next = rows_w + (size_t)s_next * stride_l;
+    sweep_row<MPL>(c0, c1, rx, rho_l, skm, rp, rp_next);
+    S = block_sum_regs<G>(red, slot, c0, c1);
+    int s_next2;
+    fetched_site<true>(s_next2, coef_j, nx_j);
+    bool rescaled = false;
+    if (out_of_range(S)) {
+      const double inv = 1.0 / S;
+      static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
+        const double f = inv;
+        state_scale<decltype(ic)::value>(f);
+      });
+      lg = log(S);
+      S = 1.0;
+      rescaled = true;
+    }
+    s_next = s_next2;
+    rp = rp_next;
+    return rescaled;
+  };
+
   if constexpr (!BWD) {
     // ---------------- forward (:786-919) ----------------
     const float* __restrict__ alpha0 = reinterpret_cast<const float*>(stone + 32);
     double prev = (double)*reinterpret_cast<const float*>(stone + 8 + 20);  // logscale of the alpha stone
     double acc = 0.0;
-    double* arow = ka.scratch + row0 * pitch + col;
+    double* arow = ka.scratch + cp0 * pitch + col;
     static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       const int n = (wbase + i) * 64 + lane;
@@ -115,7 +245,10 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
       acc += a;
     });
     double S = block_sum_regs<G>(red, slot, acc);
-    if (threadIdx.x == 0) ka.logscales[row0] = (float)prev;
+    if (threadIdx.x == 0) {
+      ka.logscales[row0] = (float)prev;
+      ka.cp_sum[cp0] = S;
+    }
     stateless();
     set_thresholds(ka.p.c.lo, ka.p.c.hi);
     int s_cur = __builtin_amdgcn_readfirstlane(dk[jb + 1]);
@@ -124,11 +257,12 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
     set_site_pointer(rec + jb + 1);
     // what every site needs from the argument segment, fetched once and opaque to the compiler: a scalar load
     // inside the loop would bring a wait for the row fetch in flight with it
-    double* scratch_rows = ka.scratch + row0 * pitch + col;
+    double* scratch_rows = ka.scratch + cp0 * pitch + col;
+    double* sums = ka.cp_sum + cp0;
     float* ls_rows = ka.logscales + row0;
     size_t pitch_l = pitch;
     int stride_l = stride;
-    asm volatile("" : "+s"(pitch_l), "+s"(stride_l), "+s"(ls_rows));
+    asm volatile("" : "+s"(pitch_l), "+s"(stride_l), "+s"(ls_rows), "+s"(sums));
     asm volatile("" : "+v"(scratch_rows));
     double rho_l = rho;
     asm volatile("" : "+v"(rho_l));
@@ -136,152 +270,213 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_kernel_r(cons
     sload_round<0, RowRounds<MPL>::size(0)>(rp);
     for (int j = 1; j < nds; j++) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
-      const double rx = S * coef_j;
-      write_stateless<MPL, false>(S, coef_j);
-      prefetch_site<true>();
-      const uint64_t skm = edge_select(j, nds - 1, sk_last);
-      prev += nx_j;
-      double c0, c1;
-      const uint64_t* rp_next = rows_w + (size_t)s_next * stride_l;
-      sweep_row<MPL>(c0, c1, rx, rho_l, skm, rp, rp_next);
-      S = block_sum_regs<G>(red, slot, c0, c1);
-      int s_next2;
-      fetched_site<true>(s_next2, coef_j, nx_j);
+      prev += nx_j;  // the gap before site j (nx_j is replaced by the next gap's inside forward_site)
       float lsj = (float)prev;  // (:839-841) the float is what the rescale term is added to
-      if (out_of_range(S)) {
-        const double inv = 1.0 / S;
-        static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
-          const double f = inv;
-          state_scale<decltype(ic)::value>(f);
-        });
-        const double lg = log(S);
+      double lg;
+      if (forward_site(j, S, coef_j, nx_j, rp, s_next, rho_l, stride_l, lg)) {
         prev += lg;
         lsj = (float)((double)lsj + lg);
-        S = 1.0;
       }
-      {
-        if (threadIdx.x == 0) as_global(ls_rows)[j] = lsj;
-        GlobalDouble* __restrict__ ar = as_global(scratch_rows + (size_t)j * pitch_l);
+      if (threadIdx.x == 0) as_global(ls_rows)[j] = lsj;
+      if (j % B == 0) {
+        GlobalDouble* __restrict__ ar = as_global(scratch_rows + (size_t)(j / B) * pitch_l);
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
           constexpr int i = decltype(ic)::value;
           ar[(size_t)i * 64] = state_get<i>();
         });
+        if (threadIdx.x == 0) as_global(sums)[j / B] = S;
       }
-      s_cur = s_next;
-      s_next = s_next2;
-      rp = rp_next;
     }
     swait();
   } else {
     // ---------------- backward (:921-1107) ----------------
+    claim_slots<MPL>();
     const double theta_d = ka.p.c.theta_d, ntheta_d = ka.p.c.ntheta_d;
     const float* __restrict__ beta0 = reinterpret_cast<const float*>(stone + 56 + (size_t)4 * N);
     const float ls_beta = *reinterpret_cast<const float*>(stone + 32 + (size_t)4 * N + 20);
     double prev = (double)ls_beta;
     const uint64_t* row_last = rows_w + (size_t)s_last * stride;
-    double acc = 0.0;
-    {
-      const double* arow = ka.scratch + (row0 + nds - 1) * pitch + col;
-      float* trow = ka.topology + (row0 + nds - 1) * pitch + col;
-      static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int i = decltype(ic)::value;
-        const int n = (wbase + i) * 64 + lane;
-        const uint64_t w = row_last[i];
-        const bool m = __builtin_amdgcn_inverse_ballot_w64(~w & sk_last);
-        const double b = (n < N && n != k) ? (double)beta0[n] : 0.0;
-        state_set<i>(b);
-        acc += (m ? theta_d : ntheta_d) * b;
-        trow[(size_t)i * 64] = (float)(arow[(size_t)i * 64] * b);
-      });
-    }
-    double B = block_sum_regs<G>(red, slot, acc);
-    if (threadIdx.x == 0) ka.logscales[row0 + nds - 1] = ka.logscales[row0 + nds - 1] + ls_beta;  // float + float (:929)
     stateless();
     set_thresholds(ka.p.c.lo, ka.p.c.hi);
     const double inv_nt = ka.p.c.inv_ntheta_d, inv_t = ka.p.c.inv_theta_d;
     const double w_all = ntheta_d, w_mis = theta_d - ntheta_d;
-    int s_cur = __builtin_amdgcn_readfirstlane(dk[je - 1]);
-    int s_prev = __builtin_amdgcn_readfirstlane(dk[je > 1 ? je - 2 : 0]);
-    double coef_j = ka.last_coef[t], nx_j = ka.last_nx[t];
-    set_site_pointer(rec + (je - 1));
-    const double* scratch_rows = ka.scratch + row0 * pitch + col;
+    const double* scratch_rows = ka.scratch + cp0 * pitch + col;
+    const double* sums = ka.cp_sum + cp0;
     float* top_rows = ka.topology + row0 * pitch + col;
     float* ls_rows = ka.logscales + row0;
     size_t pitch_l = pitch;
     int stride_l = stride;
-    asm volatile("" : "+s"(pitch_l), "+s"(stride_l), "+s"(ls_rows));
+    asm volatile("" : "+s"(pitch_l), "+s"(stride_l), "+s"(ls_rows), "+s"(sums));
     asm volatile("" : "+v"(scratch_rows), "+v"(top_rows));
     double rho_l = rho;
     asm volatile("" : "+v"(rho_l));
     const double inv_nt_s = sgpr_f64(inv_nt), inv_t_s = sgpr_f64(inv_t);
     const ScalarWeight w_all_s = {sgpr_f64(w_all)}, w_mis_s = {sgpr_f64(w_mis)};
-    const uint64_t* rp_n = row_last;
-    const uint64_t* rp_c = rows_w + (size_t)s_cur * stride_l;
-    sload_words<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
-    sload_words<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);
-    for (int j = nds - 2; j >= 0; j--) {
-      if ((j & 31) == 0) rotate_priority(rank, j, 0);
-      const double rx = B * coef_j;
-      const double aa = rx * inv_nt_s;
-      const double bb = rx * inv_t_s - aa;
-      const double c1 = bb * rho_l;
-      write_stateless<MPL, true>(rx, inv_nt_s);
-      prefetch_site<false>();
-      const uint64_t skn = edge_select(j, nds - 2, sk_last);
-      const uint64_t skc = edge_select(j, 0, sk_first);
-      prev += nx_j;
-      const float ls_fwd = as_global(ls_rows)[j];  // the forward launch's logscale of this row; asked for early
-      double a0, a1, m0 = 0.0, m1 = 0.0;
-      const uint64_t* rp_p = rows_w + (size_t)s_prev * stride_l;
-      sweep_two_rows<MPL>(a0, a1, m0, m1, aa, rho_l, c1, skn, skc, rp_n, rp_c, rp_p);
-      uint32_t B_high;
-      B = block_sum_hi<G>(red, slot, B_high, a0 + a1, w_all_s, m0 + m1, w_mis_s);
-      int s_prev2;
-      fetched_site<false>(s_prev2, coef_j, nx_j);
-      {
-        // topology row j = alpha row j * beta row j, before the beta row is rescaled (:1067-1095)
-        // the loads of the whole row go out before the first store: the two rows never overlap
-        const GlobalDouble* __restrict__ ar = as_global(scratch_rows + (size_t)j * pitch_l);
-        GlobalFloat* __restrict__ tr = as_global(top_rows + (size_t)j * pitch_l);
-        // in groups of 8 words: all loads of a group, then its products and stores (left alone, the compiler
-        // keeps two loads in flight and pays a memory round trip per word)
-        constexpr int CH = 8;
-        static_for<0, (MPL + CH - 1) / CH>([&](auto gc) __attribute__((always_inline)) {
-          constexpr int g = decltype(gc)::value;
-          constexpr int n = MPL - CH * g < CH ? MPL - CH * g : CH;
-          double av[n];
-          static_for<0, n>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            av[i] = ar[(size_t)(CH * g + i) * 64];
-          });
-          __builtin_amdgcn_sched_barrier(0);
-          static_for<0, n>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int i = decltype(ic)::value;
-            tr[(size_t)(CH * g + i) * 64] = (float)(av[i] * state_get<CH * g + i>());
-          });
-          __builtin_amdgcn_sched_barrier(0);
+    double Bs = 0.0;  // the emission-weighted sum of the beta row (:1046-1063)
+    // topology row j = alpha row j * beta row j (the state block), alpha from its checkpoint in HBM
+    auto product_from_checkpoint = [&](int j, int c) __attribute__((always_inline)) {
+      const GlobalDouble* __restrict__ ar = as_global(scratch_rows + (size_t)c * pitch_l);
+      GlobalFloat* __restrict__ tr = as_global(top_rows + (size_t)j * pitch_l);
+      // in groups of 8 words: all loads of a group, then its products and stores (left alone, the compiler
+      // keeps two loads in flight and pays a memory round trip per word)
+      constexpr int CH = 8;
+      static_for<0, (MPL + CH - 1) / CH>([&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        constexpr int n = MPL - CH * g < CH ? MPL - CH * g : CH;
+        double av[n];
+        static_for<0, n>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          av[i] = ar[(size_t)(CH * g + i) * 64];
         });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, n>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          tr[(size_t)(CH * g + i) * 64] = (float)(av[i] * state_get<CH * g + i>());
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    const int nblk = (nds + B - 1) / B;
+    for (int c = nblk - 1; c >= 0; c--) {
+      const int r0 = c * B;
+      const int r1 = r0 + B < nds ? r0 + B : nds;  // rows [r0, r1) of the section
+      if constexpr (B > 1) {
+        // beta waits in its slot while the state block runs the forward recursion over the block again
+        if (c != nblk - 1) slot_save<B - 1, MPL>();
+        {
+          // the checkpoint into the state block, eight words at a time: all loads of a group before its moves (one at a
+          // time, every word would cost a round trip to memory)
+          const GlobalDouble* __restrict__ ar = as_global(scratch_rows + (size_t)c * pitch_l);
+          constexpr int CH = 8;
+          static_for<0, (MPL + CH - 1) / CH>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int n = MPL - CH * g < CH ? MPL - CH * g : CH;
+            double av[n];
+            static_for<0, n>([&](auto ic) __attribute__((always_inline)) {
+              constexpr int i = decltype(ic)::value;
+              av[i] = ar[(size_t)(CH * g + i) * 64];
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, n>([&](auto ic) __attribute__((always_inline)) {
+              constexpr int i = decltype(ic)::value;
+              state_set<CH * g + i>(av[i]);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        if (r1 - r0 > 1) {
+          double S = sgpr_f64(as_global(sums)[c]);
+          int s_cur = __builtin_amdgcn_readfirstlane(dk[jb + r0 + 1]);
+          int s_next = __builtin_amdgcn_readfirstlane(dk[jb + r0 + 2 < nd_chunk ? jb + r0 + 2 : nd_chunk - 1]);
+          double coef_j = rec[jb + r0].coef, nx_j = rec[jb + r0].nx;
+          set_site_pointer(rec + jb + r0 + 1);
+          const uint64_t* rp = rows_w + (size_t)s_cur * stride_l;
+          sload_round<0, RowRounds<MPL>::size(0)>(rp);
+          for (int i = 1; r0 + i < r1; i++) {
+            double lg;
+            forward_site(r0 + i, S, coef_j, nx_j, rp, s_next, rho_l, stride_l, lg);
+            slot_save_at<MPL, B - 1>(i - 1);
+          }
+          swait();  // the row words asked for beyond the block: the registers go to the backward sweeps next
+        }
       }
-      float lsj = (float)((double)ls_fwd + prev);  // (:994-997)
-      if (out_of_range(B)) {
-        const double inv = 1.0 / B;
+      int jtop = r1 - 1;
+      if (c == nblk - 1) {
+        // the last row of the section: beta is the stone (:935-956), its product with alpha is taken as it stands
+        double acc = 0.0;
+        float* trow = ka.topology + (row0 + nds - 1) * pitch + col;
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
-          const double f = inv;
-          state_scale<decltype(ic)::value>(f);
+          constexpr int i = decltype(ic)::value;
+          const int n = (wbase + i) * 64 + lane;
+          const uint64_t w = row_last[i];
+          const bool m = __builtin_amdgcn_inverse_ballot_w64(~w & sk_last);
+          const double b = (n < N && n != k) ? (double)beta0[n] : 0.0;
+          state_set<i>(b);
+          acc += (m ? theta_d : ntheta_d) * b;
         });
-        const double lg = log(B);  // std::log on this side too (:1091-1092)
-        prev += lg;
-        lsj = (float)((double)lsj + lg);
-        B = 1.0;
+        // alpha of that row: the checkpoint itself if the last block has one row, else the slot filled last
+        if (B > 1 && r1 - 1 > r0) slot_product_at<MPL, B - 1>(r1 - 2 - r0, as_global(trow));
+        else product_from_checkpoint(nds - 1, c);
+        Bs = block_sum_regs<G>(red, slot, acc);
+        if (threadIdx.x == 0) ka.logscales[row0 + nds - 1] = ka.logscales[row0 + nds - 1] + ls_beta;  // float + float (:929)
+        jtop = nds - 2;
+      } else {
+        if constexpr (B > 1) slot_load<B - 1, MPL>();
       }
-      if (threadIdx.x == 0) as_global(ls_rows)[j] = lsj;
-      s_cur = s_prev;
-      s_prev = s_prev2;
-      rp_n = rp_c;
-      rp_c = rp_p;
+      if (jtop < r0) continue;  // a last block of one row
+      // the backward sweeps of rows jtop .. r0: scalars of the first step fetched here, of the others during the sweeps
+      double coef_j, nx_j;
+      if (jtop == nds - 2) {
+        coef_j = ka.last_coef[t];  // the gap after the section's last site is r[last] alone (:737-750)
+        nx_j = ka.last_nx[t];
+      } else {
+        coef_j = rec[jb + jtop + 1].coef;
+        nx_j = rec[jb + jtop + 1].nx;
+      }
+      set_site_pointer(rec + (jb + jtop));
+      int s_cur = __builtin_amdgcn_readfirstlane(dk[jb + jtop]);
+      int s_prev = __builtin_amdgcn_readfirstlane(dk[jb + jtop > 0 ? jb + jtop - 1 : 0]);
+      const uint64_t* rp_n = rows_w + (size_t)__builtin_amdgcn_readfirstlane(dk[jb + jtop + 1]) * stride_l;
+      const uint64_t* rp_c = rows_w + (size_t)s_cur * stride_l;
+      sload_words<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
+      sload_words<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);
+      for (int j = jtop; j >= r0; j--) {
+        {
+          if ((j & 31) == 0) rotate_priority(rank, j, 0);
+          const double rx = Bs * coef_j;
+          const double aa = rx * inv_nt_s;
+          const double bb = rx * inv_t_s - aa;
+          const double c1 = bb * rho_l;
+          write_stateless<MPL, true>(rx, inv_nt_s);
+          prefetch_site<false>();
+          const uint64_t skn = edge_select(j, nds - 2, sk_last);
+          const uint64_t skc = edge_select(j, 0, sk_first);
+          prev += nx_j;
+          const float ls_fwd = as_global(ls_rows)[j];  // the forward launch's logscale of this row; asked for early
+          double a0, a1, m0 = 0.0, m1 = 0.0;
+          const uint64_t* rp_p = rows_w + (size_t)s_prev * stride_l;
+          sweep_two_rows<MPL>(a0, a1, m0, m1, aa, rho_l, c1, skn, skc, rp_n, rp_c, rp_p);
+          uint32_t B_high;
+          Bs = block_sum_hi<G>(red, slot, B_high, a0 + a1, w_all_s, m0 + m1, w_mis_s);
+          int s_prev2;
+          fetched_site<false>(s_prev2, coef_j, nx_j);
+          // topology row j = alpha row j * beta row j, before the beta row is rescaled (:1067-1095)
+          if (B == 1 || j == r0) product_from_checkpoint(j, c);
+          else slot_product_at<MPL, B - 1>(j - r0 - 1, as_global(top_rows + (size_t)j * pitch_l));
+          float lsj = (float)((double)ls_fwd + prev);  // (:994-997)
+          if (out_of_range(Bs)) {
+            const double inv = 1.0 / Bs;
+            static_for<0, MPL>([&](auto wc) __attribute__((always_inline)) {
+              const double f = inv;
+              state_scale<decltype(wc)::value>(f);
+            });
+            const double lg = log(Bs);  // std::log on this side too (:1091-1092)
+            prev += lg;
+            lsj = (float)((double)lsj + lg);
+            Bs = 1.0;
+          }
+          if (threadIdx.x == 0) as_global(ls_rows)[j] = lsj;
+          s_cur = s_prev;
+          s_prev = s_prev2;
+          rp_n = rp_c;
+          rp_c = rp_p;
+        }
+      }
+      swait();  // the row words asked for beyond the block
     }
-    swait();
   }
+}
+
+// The two launches as kernels of their own: they differ in the register budget they are compiled with.
+template <int MPL, int G>
+__global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) repaint_fwd_kernel_r(const RepaintKArgs ka)
+{
+  repaint_body<MPL, G, false>(ka);
+}
+template <int MPL, int G>
+__global__ void RELATE_BWD_REPAINT_ATTR __launch_bounds__(64 * G) repaint_bwd_kernel_r(const RepaintKArgs ka)
+{
+  repaint_body<MPL, G, true>(ka);
 }
 
 typedef RepaintLaunch RepaintArgs;  // paint_kernels.h
@@ -304,6 +499,7 @@ inline hipError_t launch_repaint_t(const RepaintArgs& a, hipStream_t st)
   ka.last_coef = a.last_coef;
   ka.last_nx = a.last_nx;
   ka.scratch = a.scratch;
+  ka.cp_sum = a.cp_sum;
   ka.topology = a.topology;
   ka.logscales = a.logscales;
   ka.w = a.w;
@@ -316,10 +512,10 @@ inline hipError_t launch_repaint_t(const RepaintArgs& a, hipStream_t st)
   ka.p.K = a.K;
   ka.p.c = a.c;
   if (a.pitch != G * MPL * 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((repaint_kernel_r<MPL, G, false>), dim3((unsigned)a.K), dim3(64 * G), lds_bytes, st, ka);
+  hipLaunchKernelGGL((repaint_fwd_kernel_r<MPL, G>), dim3((unsigned)a.K), dim3(64 * G), lds_bytes, st, ka);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((repaint_kernel_r<MPL, G, true>), dim3((unsigned)a.K), dim3(64 * G), lds_bytes, st, ka);
+  hipLaunchKernelGGL((repaint_bwd_kernel_r<MPL, G>), dim3((unsigned)a.K), dim3(64 * G), lds_bytes, st, ka);
   return hipGetLastError();
 }
 

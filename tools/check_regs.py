@@ -14,7 +14,7 @@ import sys
 
 # first reserved VGPR / SGPR per kernel family (namespace of the mangled name)
 LIMITS = {"regs": (48, 52), "aloop": (24, 24)}
-REG = re.compile(r"\b([vs])(\d+)\b|\b([vs])\[(\d+):(\d+)\]")
+REG = re.compile(r"\b([vsa])(\d+)\b|\b([vsa])\[(\d+):(\d+)\]")
 
 
 def check(path):
@@ -23,10 +23,11 @@ def check(path):
     in_asm = False
     counts = {}
     for ln, line in enumerate(open(path), 1):
-        m = re.match(r"^(_ZN6relate\d+(regs|aloop)\d+(?:paint|repaint)_kernel_[ra]\w+):", line)
+        m = re.match(r"^(_ZN6relate\d+(regs|aloop)\d+(?:paint|repaint|repaint_fwd|repaint_bwd)_kernel_[ra]\w+):", line)
         if m:
             kernel = m.group(1)
             v_limit, s_limit = LIMITS[m.group(2)]
+            a_limit = None  # first reserved accumulation register, where the kernel names one
             counts[kernel] = 0
             continue
         if line.startswith("\t.end_amdhsa_kernel") or ".Lfunc_end" in line:
@@ -43,6 +44,10 @@ def check(path):
         if lim and in_asm:  # the kernel states its own limits (claim_registers)
             v_limit, s_limit = int(lim.group(1)), int(lim.group(2))
             continue
+        lim = re.search(r"relate_limits a(\d+)", line)
+        if lim and in_asm:  # (claim_slots)
+            a_limit = int(lim.group(1))
+            continue
         code = line.split(";")[0]
         if in_asm or not code.strip() or code.lstrip().startswith("."):
             continue
@@ -52,7 +57,8 @@ def check(path):
                 cls, hi = r.group(1), int(r.group(2))
             else:
                 cls, hi = r.group(3), int(r.group(5))
-            if hi >= (v_limit if cls == "v" else s_limit):
+            limit = {"v": v_limit, "s": s_limit, "a": a_limit if a_limit is not None else 1 << 30}[cls]
+            if hi >= limit:
                 bad.append(f"{path}:{ln}: {kernel[:60]}: {code.strip()}")
     return counts, bad
 

@@ -95,6 +95,65 @@ def paint_compiled(seq, r, wb, theta_p, theta_d, targets, G, MPL, asm=None, kern
     return out, stats
 
 
+def repaint_block_rows(MPL):
+    """Rows between two alpha checkpoints (relate_amd/csrc/paint_kernels.h: repaint_block_rows)."""
+    slots = (256 - 32 - (56 + 2 * MPL)) // (2 * MPL)
+    return 1 if slots < 2 else min(slots, 8)
+
+
+def repaint_compiled(seq, r, wb, theta, window, stones, targets, G, MPL, asm=None):
+    """The two compiled re-painting kernels (repaint_kernel_r<MPL, G, false / true>) interpreted for `targets` of one
+    window.  stones: the (K, 56 + 8N) records of that window for those targets (as the painting wrote them).
+    Returns (topology (rows, pitch) float32, logscales (rows,) float32, row offsets (K + 1))."""
+    import math
+    asm = asm or os.path.join(ROOT, "relate_amd", "csrc", f"paint_regs_g{G}.s")
+    ch = lists.Chunk(seq, r, wb, theta, theta)
+    targets = list(targets)
+    k0, K = targets[0], len(targets)
+    N, L, W = ch.N, ch.L, ch.W
+    if G * MPL * 64 < N or G * MPL > ch.stride:
+        raise ValueError("geometry does not fit the panel")
+    mem, _ = build_memory(ch, targets)
+    pitch = G * MPL * 64
+    B = repaint_block_rows(MPL)
+    off = np.zeros(K + 1, dtype=np.int64)
+    coef, nx = np.zeros(K), np.zeros(K)
+    c = ch.c
+    for t, k in enumerate(targets):
+        off[t + 1] = off[t] + int(ch.bej[k, window] - ch.bbj[k, window] + 1)
+        rsum = float(r[ch.dk[k][int(ch.bej[k, window])]])
+        nxv = -rsum + c["log_ntheta"]
+        rp = 1.0 - math.exp(-rsum)
+        if rp > 0.99:
+            rp, nxv = 0.99, c["log_small"] + c["log_ntheta"]
+        coef[t], nx[t] = rp / ((1.0 - rp) * c["Nm1"]), nxv
+    rows = int(off[K])
+    cp_rows = rows // B + K + 1
+    R = 56 + 8 * N
+    stones = np.ascontiguousarray(stones, dtype=np.uint8).reshape(K, R)
+    a = {name: mem.add(name, data, len(data), wr) for name, data, wr in (
+        ("stones", stones.tobytes(), False), ("row_off", off[:K].tobytes(), False), ("last_coef", coef.tobytes(), False),
+        ("last_nx", nx.tobytes(), False), ("scratch", bytes(8 * cp_rows * pitch), True), ("cp_sum", bytes(8 * cp_rows), True),
+        ("topology", bytes(4 * rows * pitch), True), ("logscales", bytes(4 * rows), True))}
+    g = {n: mem.address(n) for n in ("rows", "dk", "rec", "off", "nd", "bbj", "bej", "order")}
+    consts = struct.pack("<13dii", c["Nm1"], c["prior_mis"], c["prior_match"], c["rho"], c["log_ntheta"], c["log_small"],
+                         c["log_Nm1"], c["theta_d"], c["ntheta_d"], c["inv_theta_d"], c["inv_ntheta_d"], c["lo"], c["hi"], c["same_theta"], 0)
+    ka = struct.pack("<16Q2i6i", g["rows"], g["dk"], g["rec"], g["off"], g["nd"], g["bbj"], g["bej"], g["order"], a["stones"],
+                     a["row_off"], a["last_coef"], a["last_nx"], a["scratch"], a["cp_sum"], a["topology"], a["logscales"],
+                     window, pitch, ch.stride, N, L, W, k0, K) + consts
+    kernarg = mem.add("repaint_kernarg", ka, len(ka))
+    stats = {}
+    for bwd in (0, 1):
+        kern = emu.load_kernel(asm, rf"repaint_{'bwd' if bwd else 'fwd'}_kernel_rILi{MPL}ELi{G}E")
+        for block in range(K):
+            for w in emu.run_workgroup(kern, mem, kernarg, block, G, 2 * G * 8):
+                for key, v in w.stats.items():
+                    stats[key] = stats.get(key, 0) + v
+    top = np.frombuffer(bytes(mem.buffer("topology")), dtype=np.float32).reshape(rows, pitch)
+    ls = np.frombuffer(bytes(mem.buffer("logscales")), dtype=np.float32)
+    return top, ls, off, stats
+
+
 def main():
     from conftest import load_golden
     import oracle_lib as ol

@@ -87,6 +87,12 @@ class Memory:
                 return b[2]
         raise KeyError(name)
 
+    def address(self, name):
+        for b in self.bufs:
+            if b[0] == name:
+                return b[1]
+        raise KeyError(name)
+
 
 # ---- exact arithmetic helpers ---------------------------------------------------------------------------------
 def _f64(bits):
@@ -189,7 +195,7 @@ class Wave:
 
     # ---- operand parsing
     _sre = re.compile(r"^s(\d+)$|^s\[(\d+):(\d+)\]$")
-    _vre = re.compile(r"^v(\d+)$|^v\[(\d+):(\d+)\]$")
+    _vre = re.compile(r"^[va](\d+)$|^[va]\[(\d+):(\d+)\]$")  # a: accumulation registers, rows 256.. of the file
     _special = {"vcc": VCC, "vcc_lo": VCC, "vcc_hi": VCC + 1, "exec": EXEC, "exec_lo": EXEC, "exec_hi": EXEC + 1, "m0": M0_REG,
                 "flat_scratch": SCRATCH_LO, "flat_scratch_lo": SCRATCH_LO, "flat_scratch_hi": SCRATCH_LO + 1}
     _fconst = {"0.5": 0.5, "-0.5": -0.5, "1.0": 1.0, "-1.0": -1.0, "2.0": 2.0, "-2.0": -2.0, "4.0": 4.0, "-4.0": -4.0,
@@ -203,10 +209,11 @@ class Wave:
         return self._special.get(tok)
 
     def vreg(self, tok):
-        m = self._vre.match(tok.strip())
+        tok = tok.strip()
+        m = self._vre.match(tok)
         if not m:
             return None
-        return int(m.group(1) if m.group(1) is not None else m.group(2))
+        return int(m.group(1) if m.group(1) is not None else m.group(2)) + (256 if tok[0] == "a" else 0)
 
     def ssrc32(self, tok):
         tok = tok.strip()
@@ -578,6 +585,22 @@ class Wave:
         off, width = c & 31, (c >> 16) & 0x7F
         r = (x >> off) & ((1 << width) - 1)
         self.set_s32(self.sreg(d), r)
+        self.scc = int(r != 0)
+
+    def op_s_bfe_i64(self, d, a, b):
+        x, c = self.ssrc64(a), self.ssrc32(b)
+        off, width = c & 63, (c >> 16) & 0x7F
+        r = (x >> off) & ((1 << width) - 1)
+        if width and r >> (width - 1):
+            r -= 1 << width
+        self.set_s64(self.sreg(d), r & U64)
+        self.scc = int(r != 0)
+
+    def op_s_bfe_u64(self, d, a, b):
+        x, c = self.ssrc64(a), self.ssrc32(b)
+        off, width = c & 63, (c >> 16) & 0x7F
+        r = (x >> off) & ((1 << width) - 1)
+        self.set_s64(self.sreg(d), r)
         self.scc = int(r != 0)
 
     def op_s_sext_i32_i16(self, d, a):
@@ -1398,6 +1421,30 @@ class Wave:
                 sl = (lane & 32) | ((((lane & 31) & (off & 31)) | ((off >> 5) & 31)) ^ ((off >> 10) & 31))
             out[lane] = src[sl] if ex[sl] else 0
         self.put32(d, out)
+
+    # accumulation registers: rows 256.. of the vector register file here (the hardware's unified file)
+    @staticmethod
+    def _areg(tok):
+        m = re.fullmatch(r"a\[([^\]:]+)\]|a(\d+)", tok.strip())
+        if not m:
+            raise ValueError(f"not an accumulation register: {tok!r}")
+        n = _const_expr(m.group(1)) if m.group(1) is not None else int(m.group(2))
+        if not 0 <= n < 256:
+            raise ValueError(f"accumulation register out of range: {tok!r}")
+        return 256 + n
+
+    def op_v_accvgpr_write_b32(self, d, s):
+        r = self._areg(d)
+        vals = self.vsrc32(s)
+        ex = self.exec_mask()
+        self.v[r][ex] = np.asarray(vals, dtype=np.uint32)[ex] if np.ndim(vals) else np.uint32(vals)
+        self.vdef[r] = True
+
+    def op_v_accvgpr_read_b32(self, d, s):
+        r = self._areg(s)
+        if not self.vdef[r]:
+            raise EmuError(f"{self.name}: accumulation register read before anything wrote it: {self.line}")
+        self.put32(d, self.v[r].copy())
 
     def op_ds_permute_b32(self, d, addr, data, *m):
         ex = self.exec_mask()
