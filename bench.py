@@ -140,9 +140,11 @@ def end_to_end(ra, seq, r, wb, theta, theta_data):
 
 
 def repaint_leg(plan, torch, d_out, w, N, R, stream, reps=3):
-    """Re-painting of one window from the stones the timed steps left in HBM: per element of the topology
-    matrix the two launches write an alpha (8 B), read it back (8 B) and write the product (4 B)."""
+    """Re-painting of one window from the stones the timed steps left in HBM.  Per element of the topology matrix
+    the two launches write the product (4 B) and write and read back every B-th alpha row (16 / B bytes, B =
+    checkpoint_rows of the launch geometry; the reference's scheme, every row kept, is B = 1: 20 B)."""
     rows, pitch, _ = plan.repaint_layout(w)
+    geo = plan.repaint_geometry()
     top = torch.empty(rows * pitch, dtype=torch.float32, device="cuda")
     ls = torch.empty(rows, dtype=torch.float32, device="cuda")
     ms = []
@@ -150,8 +152,10 @@ def repaint_leg(plan, torch, d_out, w, N, R, stream, reps=3):
         plan.repaint(w, d_out.data_ptr() + w * N * R, top.data_ptr(), ls.data_ptr(), stream)
         ms.append(plan.timings()["paint_ms"])
     t = min(ms) * 1e-3
-    b_alg = 20.0 * rows * N
-    out = {"window": w, "rows": rows, "pitch": pitch, "ms": min(ms), "elements_per_s": rows * N / t,
+    per_element = 4.0 + 16.0 / geo["checkpoint_rows"]
+    b_alg = per_element * rows * N
+    out = {"window": w, "rows": rows, "pitch": pitch, "geometry": geo, "ms": min(ms), "elements_per_s": rows * N / t,
+           "bytes_per_element": per_element, "output_gb_per_s": 4.0 * rows * N / t / 1e9,
            "roofline": {"bound": "hbm", "achieved": b_alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": b_alg / t / 1e9 / HBM_PEAK_GBS, "traffic": None}}
     # distance matrix of one SNP from that topology (DistanceMeasure::GetMatrix): every other row mixed with

@@ -290,6 +290,11 @@ int relate_plan_timings(relate_plan* p, float* ms_pack, float* ms_prepare, float
  * number of targets of the range (how many rounds of waves the launch makes over the chip), so two ranges of one
  * chunk may be painted with different geometries; the records do not depend on it. */
 int relate_plan_geometry(const relate_plan* p, int* waves_per_target, int* states_per_lane);
+/* Geometry of the re-painting launches of the prepared range (its own: relate_plan_repaint_layout's pitch is
+ * 64 * waves_per_target * states_per_lane of THIS call) and the number of rows between two alpha checkpoints: the
+ * launches move 4 + 16 / checkpoint_rows bytes per topology element (1: every alpha row is kept, as
+ * FastPainting::RePaintSection keeps them, src/fast_painting.cpp:786-919). */
+int relate_plan_repaint_geometry(const relate_plan* p, int* waves_per_target, int* states_per_lane, int* checkpoint_rows);
 
 /* GPU fast_log (src/fast_log.hpp:6-21) on n floats, host in / host out: used by the parity tests. */
 int relate_fast_log(const float* in, float* out, int n, int device);

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "relate_release_host_staging": (None, []),
     "relate_plan_timings": (C.c_int, [vp, f32p, f32p, f32p]),
     "relate_plan_geometry": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "relate_plan_repaint_geometry": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "relate_fast_log": (C.c_int, [f32p, f32p, C.c_int, C.c_int]),
     "relate_synth_chunk": (C.c_int, [C.c_int, C.c_int, C.c_uint64, C.c_int, u8p, f64p]),
     "relate_write_chunk": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, u8p, f64p, C.c_int, i32p]),

@@ -1018,6 +1018,16 @@ int relate_plan_geometry(const relate_plan* p, int* waves, int* mpl)
   return RELATE_OK;
 }
 
+int relate_plan_repaint_geometry(const relate_plan* p, int* waves, int* mpl, int* checkpoint_rows)
+{
+  if (!p) return fail(RELATE_EINVAL, "null plan");
+  if (!p->have_prepare || p->geo_repaint.MPL <= 0) return fail(RELATE_EINVAL, "no targets prepared");
+  if (waves) *waves = p->geo_repaint.G;
+  if (mpl) *mpl = p->geo_repaint.MPL;
+  if (checkpoint_rows) *checkpoint_rows = relate::repaint_block_rows(p->geo_repaint.MPL);
+  return RELATE_OK;
+}
+
 int relate_fast_log(const float* in, float* out, int n, int device)
 {
   if (!in || !out || n < 0) return fail(RELATE_EINVAL, "bad argument");

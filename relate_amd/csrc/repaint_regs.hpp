@@ -340,6 +340,14 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
     for (int c = nblk - 1; c >= 0; c--) {
       const int r0 = c * B;
       const int r1 = r0 + B < nds ? r0 + B : nds;  // rows [r0, r1) of the section
+      // The first backward step of the block computes row jtop (below r0: a last block of one row, no step).  What it
+      // needs from memory is asked for here, with the loads of the forward run, so that the block pays one round trip
+      // to memory for its scalars instead of one per use.
+      const int jtop = c == nblk - 1 ? nds - 2 : r1 - 1;
+      const int jt = jtop >= r0 ? jtop : r0;  // an address inside the list when no step is taken
+      const int seed_cur = dk[jb + jt], seed_prev = dk[jb + jt > 0 ? jb + jt - 1 : 0], seed_n = dk[jb + (jt + 1 < nds ? jt + 1 : nds - 1)];
+      const double seed_coef = jtop == nds - 2 ? ka.last_coef[t] : rec[jb + jt + 1].coef;  // (:737-750) for the last site's own gap
+      const double seed_nx = jtop == nds - 2 ? ka.last_nx[t] : rec[jb + jt + 1].nx;
       if constexpr (B > 1) {
         // beta waits in its slot while the state block runs the forward recursion over the block again
         if (c != nblk - 1) slot_save<B - 1, MPL>();
@@ -380,7 +388,6 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
           swait();  // the row words asked for beyond the block: the registers go to the backward sweeps next
         }
       }
-      int jtop = r1 - 1;
       if (c == nblk - 1) {
         // the last row of the section: beta is the stone (:935-956), its product with alpha is taken as it stands
         double acc = 0.0;
@@ -399,24 +406,16 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
         else product_from_checkpoint(nds - 1, c);
         Bs = block_sum_regs<G>(red, slot, acc);
         if (threadIdx.x == 0) ka.logscales[row0 + nds - 1] = ka.logscales[row0 + nds - 1] + ls_beta;  // float + float (:929)
-        jtop = nds - 2;
       } else {
         if constexpr (B > 1) slot_load<B - 1, MPL>();
       }
       if (jtop < r0) continue;  // a last block of one row
       // the backward sweeps of rows jtop .. r0: scalars of the first step fetched here, of the others during the sweeps
-      double coef_j, nx_j;
-      if (jtop == nds - 2) {
-        coef_j = ka.last_coef[t];  // the gap after the section's last site is r[last] alone (:737-750)
-        nx_j = ka.last_nx[t];
-      } else {
-        coef_j = rec[jb + jtop + 1].coef;
-        nx_j = rec[jb + jtop + 1].nx;
-      }
+      double coef_j = seed_coef, nx_j = seed_nx;
       set_site_pointer(rec + (jb + jtop));
-      int s_cur = __builtin_amdgcn_readfirstlane(dk[jb + jtop]);
-      int s_prev = __builtin_amdgcn_readfirstlane(dk[jb + jtop > 0 ? jb + jtop - 1 : 0]);
-      const uint64_t* rp_n = rows_w + (size_t)__builtin_amdgcn_readfirstlane(dk[jb + jtop + 1]) * stride_l;
+      int s_cur = __builtin_amdgcn_readfirstlane(seed_cur);
+      int s_prev = __builtin_amdgcn_readfirstlane(seed_prev);
+      const uint64_t* rp_n = rows_w + (size_t)__builtin_amdgcn_readfirstlane(seed_n) * stride_l;
       const uint64_t* rp_c = rows_w + (size_t)s_cur * stride_l;
       sload_words<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
       sload_words<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);

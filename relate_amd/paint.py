@@ -203,6 +203,11 @@ class Plan:
         check(lib().relate_plan_geometry(self._h, C.byref(g), C.byref(m)))
         return {"waves_per_target": g.value, "states_per_lane": m.value}
 
+    def repaint_geometry(self):
+        g, m, b = C.c_int(), C.c_int(), C.c_int()
+        check(lib().relate_plan_repaint_geometry(self._h, C.byref(g), C.byref(m), C.byref(b)))
+        return {"waves_per_target": g.value, "states_per_lane": m.value, "checkpoint_rows": b.value}
+
 
 def distance_matrix_noalloc(device, N, d_topology, pitch, d_logscales, total_rows, row_index, interpolate, weight_left,
                             weight_right, d_matrix, stream=0):

@@ -68,6 +68,36 @@ def test_several_waves_and_several_rounds(N, G, MPL, tp, td):
         same_records(out, want)
 
 
+@pytest.mark.parametrize("N,L,G,MPL,k0,theta,mode", [(130, 400, 1, 4, 127, 0.025, "skew"), (600, 300, 2, 8, 62, 0.001, "flat"),
+                                                     (1100, 200, 1, 20, 0, 0.001, "skew"), (2000, 300, 2, 16, 1998, 0.001, "flat"),
+                                                     (4900, 200, 4, 20, 0, 0.001, "skew")])
+def test_repainting_kernels_from_checkpoints(N, L, G, MPL, k0, theta, mode):
+    """repaint_fwd_kernel_r / repaint_bwd_kernel_r as compiled: the forward launch keeps every B-th alpha row, the
+    backward launch recomputes the others into accumulation registers (the interpreter keeps them apart from the
+    compiler's own and checks every access); topology rows and logscales against the re-painting oracle bit for bit.
+    Geometries of the benchmark's windows among them (2 x 16 words: N = 2000; 4 x 20: N = 5008), several blocks per
+    section, rescales inside sections (skewed map)."""
+    import emu_kernel as ek
+    K = 2
+    seq, r, wb = sy.make_chunk(N=N, L=L, W=2, seed=N, r_mode=mode)
+    stones = ol.oracle().paint_stones(seq, r, theta, theta, wb, k0, k0 + K)
+    blocks = 0
+    for w in range(2):
+        top, ls, off, _ = ek.repaint_compiled(seq, r, wb, theta, w, stones[w], range(k0, k0 + K), G, MPL)
+        d = ol.decode_records(stones[w:w + 1])
+        for t in range(K):
+            want_top, want_ls = ol.oracle().repaint_section(seq, r, theta, int(d["a_snp"][0, t]), int(d["b_snp"][0, t]),
+                                                            d["alpha"][0, t], d["beta"][0, t], float(d["a_ls"][0, t]),
+                                                            float(d["b_ls"][0, t]), k0 + t)
+            got_top, got_ls = top[off[t]:off[t + 1]], ls[off[t]:off[t + 1]]
+            assert len(want_top) == off[t + 1] - off[t]
+            assert np.array_equal(got_top[:, :N].view(np.uint32), want_top.view(np.uint32))
+            assert np.array_equal(got_ls.view(np.uint32), want_ls.view(np.uint32))
+            assert np.all(got_top[:, N:] == 0)
+            blocks = max(blocks, -(-len(want_top) // ek.repaint_block_rows(MPL)))
+    assert ek.repaint_block_rows(MPL) > 1 and blocks > 1
+
+
 # ---- the plain kernels (paint_kernels.s) ------------------------------------------------------------------------
 PLAIN = os.path.join(CSRC, "paint_kernels.s")
 plain = pytest.mark.skipif(not os.path.exists(PLAIN), reason="no device assembly of the plain kernels here")

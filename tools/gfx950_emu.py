@@ -1440,6 +1440,14 @@ class Wave:
         self.v[r][ex] = np.asarray(vals, dtype=np.uint32)[ex] if np.ndim(vals) else np.uint32(vals)
         self.vdef[r] = True
 
+    def op_v_accvgpr_mov_b32(self, d, s):
+        r, q = self._areg(d), self._areg(s)
+        if not self.vdef[q]:
+            raise EmuError(f"{self.name}: accumulation register read before anything wrote it: {self.line}")
+        ex = self.exec_mask()
+        self.v[r][ex] = self.v[q][ex]
+        self.vdef[r] = True
+
     def op_v_accvgpr_read_b32(self, d, s):
         r = self._areg(s)
         if not self.vdef[r]:
