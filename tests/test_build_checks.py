@@ -39,3 +39,26 @@ def test_checker_flags_a_violation(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_regs.py"), str(bad)],
                        capture_output=True, text=True)
     assert p.returncode == 1 and "v[60:61]" in p.stderr and "s30" in p.stderr and "v20" not in p.stderr
+
+
+def test_checker_reads_the_limits_a_kernel_states(tmp_path):
+    """A kernel may state its own limits in its assembly (claim_registers / claim_slots): the compiler's scalar limit
+    where it differs from the default, and the first accumulation register the asm addresses by number."""
+    src = ("_ZN6relate4regs20repaint_bwd_kernel_rILi16ELi2EEEvNS0_12RepaintKArgsE:\n"
+           "\t;;#ASMSTART\n\t; relate_limits v48 s44\n\t;;#ASMEND\n"
+           "\t;;#ASMSTART\n\t; relate_limits a32\n\t;;#ASMEND\n"
+           "\tv_accvgpr_write_b32 a31, v2\n"        # the compiler's own AGPRs: fine
+           "\ts_mov_b32 s43, s2\n"
+           "\t;;#ASMSTART\n\tv_accvgpr_write_b32 a[40], v[56]\n\t;;#ASMEND\n"
+           "%s"
+           "\t.end_amdhsa_kernel\n")
+    ok, bad_a, bad_s = tmp_path / "ok.s", tmp_path / "bad_a.s", tmp_path / "bad_s.s"
+    ok.write_text(src % "")
+    bad_a.write_text(src % "\tv_accvgpr_read_b32 v3, a40\n")
+    bad_s.write_text(src % "\ts_mov_b32 s44, s2\n")
+    run = lambda f: subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_regs.py"), str(f)],  # noqa: E731
+                                   capture_output=True, text=True)
+    assert run(ok).returncode == 0
+    for f, what in ((bad_a, "a40"), (bad_s, "s44")):
+        p = run(f)
+        assert p.returncode == 1 and what in p.stderr
