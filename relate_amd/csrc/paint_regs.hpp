@@ -473,13 +473,17 @@ __device__ __forceinline__ void row_acc(double& c0, double& c1)
 {
   static_assert(!FIRST || NW >= 2, "the first words initialise both accumulators");
 #define RELATE_OPS : [c0] "+v"(c0), [c1] "+v"(c1) : [r] "n"(kA0 + 2 * W0)
-  if constexpr (NW == 4 && FIRST) asm volatile(RELATE_FWD_SUM2(c0, 0, 2) RELATE_FWD_SUM2(c1, 1, 3) RELATE_OPS);
+  // the first words only write the accumulators: as outputs, so that what the variables held before (nothing, at the
+  // first site of a loop) is not a value the compiler carries round the loop
+#define RELATE_OPS_FIRST : [c0] "=v"(c0), [c1] "=v"(c1) : [r] "n"(kA0 + 2 * W0)
+  if constexpr (NW == 4 && FIRST) asm volatile(RELATE_FWD_SUM2(c0, 0, 2) RELATE_FWD_SUM2(c1, 1, 3) RELATE_OPS_FIRST);
   else if constexpr (NW == 4) asm volatile(RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_FWD_ACC(c1, 3) RELATE_OPS);
-  else if constexpr (NW == 3 && FIRST) asm volatile(RELATE_FWD_SUM2(c0, 0, 2) RELATE_FWD_SET(c1, 1) RELATE_OPS);
+  else if constexpr (NW == 3 && FIRST) asm volatile(RELATE_FWD_SUM2(c0, 0, 2) RELATE_FWD_SET(c1, 1) RELATE_OPS_FIRST);
   else if constexpr (NW == 3) asm volatile(RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_FWD_ACC(c0, 2) RELATE_OPS);
-  else if constexpr (NW == 2 && FIRST) asm volatile(RELATE_FWD_SET(c0, 0) RELATE_FWD_SET(c1, 1) RELATE_OPS);
+  else if constexpr (NW == 2 && FIRST) asm volatile(RELATE_FWD_SET(c0, 0) RELATE_FWD_SET(c1, 1) RELATE_OPS_FIRST);
   else if constexpr (NW == 2) asm volatile(RELATE_FWD_ACC(c0, 0) RELATE_FWD_ACC(c1, 1) RELATE_OPS);
   else asm volatile(RELATE_FWD_ACC(c0, 0) RELATE_OPS);
+#undef RELATE_OPS_FIRST
 #undef RELATE_OPS
 }
 

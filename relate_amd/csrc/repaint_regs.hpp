@@ -118,6 +118,27 @@ __device__ __forceinline__ GlobalDouble* as_global(double* p) { return (GlobalDo
 __device__ __forceinline__ const GlobalDouble* as_global(const double* p) { return (const GlobalDouble*)p; }
 __device__ __forceinline__ GlobalFloat* as_global(float* p) { return (GlobalFloat*)p; }
 
+// Element of a row for this lane: `row` is the same in every lane (it lives in scalar registers), `lane_bytes` the
+// lane's offset in it; the access becomes scalar base + 32-bit vector offset, and no lane keeps a 64-bit pointer.
+template <class T>
+__device__ __forceinline__ T* at_lane(T* row, uint32_t lane_bytes)
+{
+  // (opaque at every use: hoisted out of a loop, the zero-extended offset would become a 64-bit register pair of its
+  // own and the access a vector-address one)
+  asm volatile("" : "+v"(lane_bytes));
+  return (T*)((__attribute__((address_space(1))) char*)row + lane_bytes);
+}
+// One float through the scalar cache into s[kSkEdge] (free in these kernels: their edge masks travel as arguments).
+// Ask for it before a sweep and take it after: the sweep's first wait for its row words covers it.  A vector load
+// here would be waited for together with every store of the row before -- a round trip to memory per row.
+__device__ __forceinline__ void sload_float(const float* p) { asm volatile("s_load_dword s[%1], %0, 0x0" ::"s"(p), "n"(kSkEdge) : "memory"); }
+__device__ __forceinline__ float sloaded_float()
+{
+  uint32_t x;
+  asm volatile("s_mov_b32 %0, s[%1]" : "=s"(x) : "n"(kSkEdge));
+  return __uint_as_float(x);
+}
+
 template <int I>
 __device__ __forceinline__ double state_get()
 {
@@ -135,15 +156,15 @@ __device__ __forceinline__ void slot_save_at(int s)
     if (s == decltype(sc)::value) slot_save<decltype(sc)::value, MPL>();
   });
 }
-// row `tr` (this lane's column, words 64 floats apart) = float(slot s * state block)
+// row `row` (uniform; this lane's column at `lane_bytes`, words 64 floats apart) = float(slot s * state block)
 template <int MPL, int NS>
-__device__ __forceinline__ void slot_product_at(int s, GlobalFloat* __restrict__ tr)
+__device__ __forceinline__ void slot_product_at(int s, GlobalFloat* row, uint32_t lane_bytes)
 {
   static_for<0, NS>([&](auto sc) __attribute__((always_inline)) {
     if (s == decltype(sc)::value) {
       static_for<0, MPL>([&](auto wc) __attribute__((always_inline)) {
         constexpr int wd = decltype(wc)::value;
-        tr[(size_t)wd * 64] = slot_times_state<decltype(sc)::value, wd, MPL>();
+        at_lane(row, lane_bytes)[(size_t)wd * 64] = slot_times_state<decltype(sc)::value, wd, MPL>();
       });
     }
   });
@@ -300,14 +321,17 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
     set_thresholds(ka.p.c.lo, ka.p.c.hi);
     const double inv_nt = ka.p.c.inv_ntheta_d, inv_t = ka.p.c.inv_theta_d;
     const double w_all = ntheta_d, w_mis = theta_d - ntheta_d;
-    const double* scratch_rows = ka.scratch + cp0 * pitch + col;
+    // rows of the checkpoints and of the topology as uniform pointers plus this lane's byte offset in a float row
+    const double* scratch_rows = ka.scratch + cp0 * pitch;
     const double* sums = ka.cp_sum + cp0;
-    float* top_rows = ka.topology + row0 * pitch + col;
+    float* top_rows = ka.topology + row0 * pitch;
     float* ls_rows = ka.logscales + row0;
     size_t pitch_l = pitch;
     int stride_l = stride;
+    uint32_t col4 = 4u * (uint32_t)col;
     asm volatile("" : "+s"(pitch_l), "+s"(stride_l), "+s"(ls_rows), "+s"(sums));
-    asm volatile("" : "+v"(scratch_rows), "+v"(top_rows));
+    asm volatile("" : "+s"(scratch_rows), "+s"(top_rows));
+    asm volatile("" : "+v"(col4));
     double rho_l = rho;
     asm volatile("" : "+v"(rho_l));
     const double inv_nt_s = sgpr_f64(inv_nt), inv_t_s = sgpr_f64(inv_t);
@@ -315,8 +339,8 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
     double Bs = 0.0;  // the emission-weighted sum of the beta row (:1046-1063)
     // topology row j = alpha row j * beta row j (the state block), alpha from its checkpoint in HBM
     auto product_from_checkpoint = [&](int j, int c) __attribute__((always_inline)) {
-      const GlobalDouble* __restrict__ ar = as_global(scratch_rows + (size_t)c * pitch_l);
-      GlobalFloat* __restrict__ tr = as_global(top_rows + (size_t)j * pitch_l);
+      const GlobalDouble* __restrict__ ar = at_lane(as_global(scratch_rows + (size_t)c * pitch_l), 2u * col4);
+      GlobalFloat* __restrict__ tr = at_lane(as_global(top_rows + (size_t)j * pitch_l), col4);
       // in groups of 8 words: all loads of a group, then its products and stores (left alone, the compiler
       // keeps two loads in flight and pays a memory round trip per word)
       constexpr int CH = 8;
@@ -354,7 +378,7 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
         {
           // the checkpoint into the state block, eight words at a time: all loads of a group before its moves (one at a
           // time, every word would cost a round trip to memory)
-          const GlobalDouble* __restrict__ ar = as_global(scratch_rows + (size_t)c * pitch_l);
+          const GlobalDouble* __restrict__ ar = at_lane(as_global(scratch_rows + (size_t)c * pitch_l), 2u * col4);
           constexpr int CH = 8;
           static_for<0, (MPL + CH - 1) / CH>([&](auto gc) __attribute__((always_inline)) {
             constexpr int g = decltype(gc)::value;
@@ -391,7 +415,7 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
       if (c == nblk - 1) {
         // the last row of the section: beta is the stone (:935-956), its product with alpha is taken as it stands
         double acc = 0.0;
-        float* trow = ka.topology + (row0 + nds - 1) * pitch + col;
+        GlobalFloat* trow = as_global(top_rows + (size_t)(nds - 1) * pitch_l);
         static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
           constexpr int i = decltype(ic)::value;
           const int n = (wbase + i) * 64 + lane;
@@ -402,7 +426,7 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
           acc += (m ? theta_d : ntheta_d) * b;
         });
         // alpha of that row: the checkpoint itself if the last block has one row, else the slot filled last
-        if (B > 1 && r1 - 1 > r0) slot_product_at<MPL, B - 1>(r1 - 2 - r0, as_global(trow));
+        if (B > 1 && r1 - 1 > r0) slot_product_at<MPL, B - 1>(r1 - 2 - r0, trow, col4);
         else product_from_checkpoint(nds - 1, c);
         Bs = block_sum_regs<G>(red, slot, acc);
         if (threadIdx.x == 0) ka.logscales[row0 + nds - 1] = ka.logscales[row0 + nds - 1] + ls_beta;  // float + float (:929)
@@ -431,17 +455,18 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
           const uint64_t skn = edge_select(j, nds - 2, sk_last);
           const uint64_t skc = edge_select(j, 0, sk_first);
           prev += nx_j;
-          const float ls_fwd = as_global(ls_rows)[j];  // the forward launch's logscale of this row; asked for early
+          sload_float(ls_rows + j);  // the forward launch's logscale of this row
           double a0, a1, m0 = 0.0, m1 = 0.0;
           const uint64_t* rp_p = rows_w + (size_t)s_prev * stride_l;
           sweep_two_rows<MPL>(a0, a1, m0, m1, aa, rho_l, c1, skn, skc, rp_n, rp_c, rp_p);
           uint32_t B_high;
           Bs = block_sum_hi<G>(red, slot, B_high, a0 + a1, w_all_s, m0 + m1, w_mis_s);
+          const float ls_fwd = sloaded_float();
           int s_prev2;
           fetched_site<false>(s_prev2, coef_j, nx_j);
           // topology row j = alpha row j * beta row j, before the beta row is rescaled (:1067-1095)
           if (B == 1 || j == r0) product_from_checkpoint(j, c);
-          else slot_product_at<MPL, B - 1>(j - r0 - 1, as_global(top_rows + (size_t)j * pitch_l));
+          else slot_product_at<MPL, B - 1>(j - r0 - 1, as_global(top_rows + (size_t)j * pitch_l), col4);
           float lsj = (float)((double)ls_fwd + prev);  // (:994-997)
           if (out_of_range(Bs)) {
             const double inv = 1.0 / Bs;
