@@ -139,6 +139,113 @@ __device__ __forceinline__ float sloaded_float()
   return __uint_as_float(x);
 }
 
+// Row of doubles -> state block without a compiler register in between: word i of this lane from the uniform pointer
+// `row` (scalar base, the lane's byte offset, word offsets as immediates; a new base every 8 words keeps them inside
+// the 12 bits of the instruction).  The caller waits (state_loads_wait) once every load of the row is on its way.
+template <int MPL>
+__device__ __forceinline__ void state_load_row(const GlobalDouble* row, uint32_t lane_bytes8)
+{
+  static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const GlobalDouble* base = row + (size_t)(i / 8) * 512;
+    const uint32_t o = lane_bytes8;  // (a lambda's asm operands must be its own variables)
+    asm volatile("global_load_dwordx2 v[%0:%0+1], %1, %2 offset:%3" ::"n"(kA0 + 2 * i), "v"(o), "s"(base), "n"((i % 8) * 512) : "memory");
+  });
+}
+__device__ __forceinline__ void state_loads_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The state block parked in LDS and multiplied from there: word i of lane l of wave w at park + ((w*MPL + i)*64 + l)*8
+// (every lane reads back what it wrote itself: no barrier).  parked_product leaves float(parked word * state word) of
+// every word in the row `row`; the reads go two at a time through v[kX], v[kT] with a full wait each (a scalar load
+// may be in flight, and those return in no order, so a counted wait would prove nothing).
+template <int MPL>
+__device__ __forceinline__ void park_state(uint32_t park_addr)
+{
+  static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int i = decltype(ic)::value;
+    const uint32_t a = park_addr;
+    asm volatile("ds_write_b64 %0, v[%1:%1+1] offset:%2" ::"v"(a), "n"(kA0 + 2 * i), "n"(i * 512) : "memory");
+  });
+}
+template <int MPL>
+__device__ __forceinline__ void parked_product(uint32_t park_addr, GlobalFloat* row, uint32_t lane_bytes)
+{
+  static_for<0, (MPL + 1) / 2>([&](auto pc) __attribute__((always_inline)) {
+    constexpr int i = 2 * decltype(pc)::value;
+    float f0, f1;
+    const uint32_t pa = park_addr, lb = lane_bytes;
+    GlobalFloat* const rw = row;
+    if constexpr (i + 1 < MPL) {
+      asm volatile(
+          "ds_read_b64 v[%[x]:%[x]+1], %[a] offset:%[o0]\n\t"
+          "ds_read_b64 v[%[t]:%[t]+1], %[a] offset:%[o1]\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_mul_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[s0]:%[s0]+1]\n\t"
+          "v_mul_f64 v[%[t]:%[t]+1], v[%[t]:%[t]+1], v[%[s1]:%[s1]+1]\n\t"
+          "v_cvt_f32_f64 %[f0], v[%[x]:%[x]+1]\n\t"
+          "v_cvt_f32_f64 %[f1], v[%[t]:%[t]+1]"
+          : [f0] "=&v"(f0), [f1] "=&v"(f1)
+          : [a] "v"(pa), [x] "n"(kX), [t] "n"(kT), [o0] "n"(i * 512), [o1] "n"((i + 1) * 512), [s0] "n"(kA0 + 2 * i),
+            [s1] "n"(kA0 + 2 * i + 2)
+          : "memory");
+      at_lane(rw, lb)[(size_t)i * 64] = f0;
+      at_lane(rw, lb)[(size_t)(i + 1) * 64] = f1;
+    } else {
+      asm volatile(
+          "ds_read_b64 v[%[x]:%[x]+1], %[a] offset:%[o0]\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_mul_f64 v[%[x]:%[x]+1], v[%[x]:%[x]+1], v[%[s0]:%[s0]+1]\n\t"
+          "v_cvt_f32_f64 %[f0], v[%[x]:%[x]+1]"
+          : [f0] "=&v"(f0)
+          : [a] "v"(pa), [x] "n"(kX), [o0] "n"(i * 512), [s0] "n"(kA0 + 2 * i)
+          : "memory");
+      at_lane(rw, lb)[(size_t)i * 64] = f0;
+    }
+  });
+}
+// What a block of the backward launch needs from the lists, through the scalar cache and with one wait for all of
+// it (as vector loads, each waits for every store issued before it, and there are a dozen of them).  The memory
+// behind these pointers was written by earlier launches.
+typedef uint32_t __attribute__((ext_vector_type(4))) Quad;
+struct BlockSeeds {
+  int dk_prev, dk_cur, dk_next;  // list entries around the first backward step
+  int dk_f1, dk_f2;              // the first two sites of the forward run
+  double coef_top, nx_top;       // record after the first backward step's site
+  double coef_f, nx_f;           // record of the block's first row
+  double sum;                    // the checkpoint's sum
+};
+__device__ __forceinline__ BlockSeeds load_block_seeds(const int32_t* p_prev, const int32_t* p_cur, const int32_t* p_next, const int32_t* p_f1,
+                                                       const int32_t* p_f2, const SiteRec* r_top, const SiteRec* r_f, const double* p_sum)
+{
+  uint32_t a, b, c, d, e;
+  Quad qt, qf;
+  uint64_t sm;
+  asm volatile(
+      "s_load_dword %0, %8, 0x0\n\t"
+      "s_load_dword %1, %9, 0x0\n\t"
+      "s_load_dword %2, %10, 0x0\n\t"
+      "s_load_dword %3, %11, 0x0\n\t"
+      "s_load_dword %4, %12, 0x0\n\t"
+      "s_load_dwordx4 %5, %13, 0x0\n\t"
+      "s_load_dwordx4 %6, %14, 0x0\n\t"
+      "s_load_dwordx2 %7, %15, 0x0\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d), "=&s"(e), "=&s"(qt), "=&s"(qf), "=&s"(sm)
+      : "s"(p_prev), "s"(p_cur), "s"(p_next), "s"(p_f1), "s"(p_f2), "s"(r_top), "s"(r_f), "s"(p_sum)
+      : "memory");
+  BlockSeeds r;
+  r.dk_prev = (int)a;
+  r.dk_cur = (int)b;
+  r.dk_next = (int)c;
+  r.dk_f1 = (int)d;
+  r.dk_f2 = (int)e;
+  r.coef_top = __hiloint2double((int)qt.y, (int)qt.x);
+  r.nx_top = __hiloint2double((int)qt.w, (int)qt.z);
+  r.coef_f = __hiloint2double((int)qf.y, (int)qf.x);
+  r.nx_f = __hiloint2double((int)qf.w, (int)qf.z);
+  r.sum = __longlong_as_double((long long)sm);
+  return r;
+}
+
 template <int I>
 __device__ __forceinline__ double state_get()
 {
@@ -360,6 +467,12 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
         __builtin_amdgcn_sched_barrier(0);
       });
     };
+    // this lane's place in the parked checkpoint row (after the 2 x G doubles of the block sums)
+    uint32_t park_addr = (uint32_t)(uintptr_t)(lds_dyn + 2 * G) + 8u * ((uint32_t)wbase * 64u + (uint32_t)lane);
+    asm volatile("" : "+v"(park_addr));
+    const double last_coef = sgpr_f64(ka.last_coef[t]), last_nx = sgpr_f64(ka.last_nx[t]);  // (:737-750) the last site's own gap
+    const int32_t* dk_s = reinterpret_cast<const int32_t*>(sgpr64((uint64_t)(uintptr_t)(dk + jb)));
+    const SiteRec* rec_s = reinterpret_cast<const SiteRec*>(sgpr64((uint64_t)(uintptr_t)(rec + jb)));
     const int nblk = (nds + B - 1) / B;
     for (int c = nblk - 1; c >= 0; c--) {
       const int r0 = c * B;
@@ -369,39 +482,27 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
       // to memory for its scalars instead of one per use.
       const int jtop = c == nblk - 1 ? nds - 2 : r1 - 1;
       const int jt = jtop >= r0 ? jtop : r0;  // an address inside the list when no step is taken
-      const int seed_cur = dk[jb + jt], seed_prev = dk[jb + jt > 0 ? jb + jt - 1 : 0], seed_n = dk[jb + (jt + 1 < nds ? jt + 1 : nds - 1)];
-      const double seed_coef = jtop == nds - 2 ? ka.last_coef[t] : rec[jb + jt + 1].coef;  // (:737-750) for the last site's own gap
-      const double seed_nx = jtop == nds - 2 ? ka.last_nx[t] : rec[jb + jt + 1].nx;
+      // (every address stays inside the target's lists, also where the value is not used)
+      const int i_f1 = jb + r0 + 1 < nd_chunk ? r0 + 1 : nd_chunk - 1 - jb, i_f2 = jb + r0 + 2 < nd_chunk ? r0 + 2 : nd_chunk - 1 - jb;
+      const BlockSeeds seeds = load_block_seeds(dk_s + (jb + jt > 0 ? jt - 1 : -jb), dk_s + jt, dk_s + (jt + 1 < nds ? jt + 1 : nds - 1), dk_s + i_f1,
+                                                dk_s + i_f2, rec_s + (jt + 1 < nds ? jt + 1 : nds - 1), rec_s + r0, sums + c);
+      const int seed_cur = seeds.dk_cur, seed_prev = seeds.dk_prev, seed_n = seeds.dk_next;
+      const double seed_coef = jtop == nds - 2 ? last_coef : seeds.coef_top;
+      const double seed_nx = jtop == nds - 2 ? last_nx : seeds.nx_top;
       if constexpr (B > 1) {
         // beta waits in its slot while the state block runs the forward recursion over the block again
         if (c != nblk - 1) slot_save<B - 1, MPL>();
-        {
-          // the checkpoint into the state block, eight words at a time: all loads of a group before its moves (one at a
-          // time, every word would cost a round trip to memory)
-          const GlobalDouble* __restrict__ ar = at_lane(as_global(scratch_rows + (size_t)c * pitch_l), 2u * col4);
-          constexpr int CH = 8;
-          static_for<0, (MPL + CH - 1) / CH>([&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value;
-            constexpr int n = MPL - CH * g < CH ? MPL - CH * g : CH;
-            double av[n];
-            static_for<0, n>([&](auto ic) __attribute__((always_inline)) {
-              constexpr int i = decltype(ic)::value;
-              av[i] = ar[(size_t)(CH * g + i) * 64];
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, n>([&](auto ic) __attribute__((always_inline)) {
-              constexpr int i = decltype(ic)::value;
-              state_set<CH * g + i>(av[i]);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-          });
-        }
+        // the checkpoint into the state block (one round trip to memory for the whole row), and a copy of it into LDS
+        // for the product of the block's first row, which is the last one the backward sweeps reach
+        state_load_row<MPL>(as_global(scratch_rows + (size_t)c * pitch_l), 2u * col4);
+        state_loads_wait();
+        park_state<MPL>(park_addr);
         if (r1 - r0 > 1) {
-          double S = sgpr_f64(as_global(sums)[c]);
-          int s_cur = __builtin_amdgcn_readfirstlane(dk[jb + r0 + 1]);
-          int s_next = __builtin_amdgcn_readfirstlane(dk[jb + r0 + 2 < nd_chunk ? jb + r0 + 2 : nd_chunk - 1]);
-          double coef_j = rec[jb + r0].coef, nx_j = rec[jb + r0].nx;
-          set_site_pointer(rec + jb + r0 + 1);
+          double S = seeds.sum;
+          int s_cur = seeds.dk_f1;
+          int s_next = seeds.dk_f2;
+          double coef_j = seeds.coef_f, nx_j = seeds.nx_f;
+          set_site_pointer(rec_s + r0 + 1);
           const uint64_t* rp = rows_w + (size_t)s_cur * stride_l;
           sload_round<0, RowRounds<MPL>::size(0)>(rp);
           for (int i = 1; r0 + i < r1; i++) {
@@ -436,10 +537,10 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
       if (jtop < r0) continue;  // a last block of one row
       // the backward sweeps of rows jtop .. r0: scalars of the first step fetched here, of the others during the sweeps
       double coef_j = seed_coef, nx_j = seed_nx;
-      set_site_pointer(rec + (jb + jtop));
-      int s_cur = __builtin_amdgcn_readfirstlane(seed_cur);
-      int s_prev = __builtin_amdgcn_readfirstlane(seed_prev);
-      const uint64_t* rp_n = rows_w + (size_t)__builtin_amdgcn_readfirstlane(seed_n) * stride_l;
+      set_site_pointer(rec_s + jtop);
+      int s_cur = seed_cur;
+      int s_prev = seed_prev;
+      const uint64_t* rp_n = rows_w + (size_t)seed_n * stride_l;
       const uint64_t* rp_c = rows_w + (size_t)s_cur * stride_l;
       sload_words<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
       sload_words<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);
@@ -465,7 +566,8 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
           int s_prev2;
           fetched_site<false>(s_prev2, coef_j, nx_j);
           // topology row j = alpha row j * beta row j, before the beta row is rescaled (:1067-1095)
-          if (B == 1 || j == r0) product_from_checkpoint(j, c);
+          if constexpr (B == 1) product_from_checkpoint(j, c);
+          else if (j == r0) parked_product<MPL>(park_addr, as_global(top_rows + (size_t)j * pitch_l), col4);
           else slot_product_at<MPL, B - 1>(j - r0 - 1, as_global(top_rows + (size_t)j * pitch_l), col4);
           float lsj = (float)((double)ls_fwd + prev);  // (:994-997)
           if (out_of_range(Bs)) {
@@ -539,7 +641,14 @@ inline hipError_t launch_repaint_t(const RepaintArgs& a, hipStream_t st)
   hipLaunchKernelGGL((repaint_fwd_kernel_r<MPL, G>), dim3((unsigned)a.K), dim3(64 * G), lds_bytes, st, ka);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((repaint_bwd_kernel_r<MPL, G>), dim3((unsigned)a.K), dim3(64 * G), lds_bytes, st, ka);
+  // the backward launch parks one row of the state block per workgroup behind the block sums
+  constexpr size_t lds_bwd = lds_bytes + (repaint_block(MPL) > 1 ? (size_t)G * MPL * 512 : 0);
+  static_assert(lds_bwd <= 160 * 1024, "LDS of a CU");
+  if (lds_bwd > 48 * 1024) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&repaint_bwd_kernel_r<MPL, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bwd);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((repaint_bwd_kernel_r<MPL, G>), dim3((unsigned)a.K), dim3(64 * G), lds_bwd, st, ka);
   return hipGetLastError();
 }
 

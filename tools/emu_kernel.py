@@ -146,7 +146,9 @@ def repaint_compiled(seq, r, wb, theta, window, stones, targets, G, MPL, asm=Non
     for bwd in (0, 1):
         kern = emu.load_kernel(asm, rf"repaint_{'bwd' if bwd else 'fwd'}_kernel_rILi{MPL}ELi{G}E")
         for block in range(K):
-            for w in emu.run_workgroup(kern, mem, kernarg, block, G, 2 * G * 8):
+            # LDS as the launcher sizes it: the block sums, and behind them the row the backward launch parks (blocks of > 1 row)
+            lds = 2 * G * 8 + (G * MPL * 512 if bwd and repaint_block_rows(MPL) > 1 else 0)
+            for w in emu.run_workgroup(kern, mem, kernarg, block, G, lds):
                 for key, v in w.stats.items():
                     stats[key] = stats.get(key, 0) + v
     top = np.frombuffer(bytes(mem.buffer("topology")), dtype=np.float32).reshape(rows, pitch)
