@@ -635,22 +635,25 @@ PaintGeometry choose_geometry(int N, int prefer_waves, int variant)
   return {G0, 0};  // MPL == 0: N too large for this variant
 }
 
-// Geometry for a launch of K targets: the rule of choose_geometry, unless a model of the launch says that
-// another wave count is clearly (7 %) faster.  All targets of a chunk take about the same time, so a launch
-// runs in rounds: 2 K G waves (a forward and a backward workgroup per target) over 1024 SIMDs x the waves per
-// SIMD that registers and LDS allow (waves_per_cu), fewer if the launch does not fill the chip.
+// Geometry for a launch of K targets: the wave count that a model of the launch prices lowest (the rule of
+// choose_geometry where the model sees no difference, and beyond the panel sizes it was fitted on).  All targets
+// of a chunk take about the same time, so a launch runs in rounds: 2 K G waves (a forward and a backward workgroup
+// per target) over 1024 SIMDs x the waves per SIMD that registers and LDS allow (waves_per_cu), fewer if the launch
+// does not fill the chip.
 // Time per site of a round = the larger of
 //   issue:   waves per SIMD x instructions per site x ns per issue slot, with 3 instructions per word + 24
-//            (+ 29, 20, 49 for the exchange between 2, 4, 8 waves) and 3.45, 2.73, 2.24, 2.09, 1.89 ns per slot
+//            (+ 10, 14, 21 for the exchange between 2, 4, 8 waves) and 3.45, 2.73, 2.24, 2.09, 1.89 ns per slot
 //            at 2, 3, 4, 5, 6 or more waves per SIMD;
-//   latency: the dependent chain of one site, 300 + 10.5 ns per word for one wave, 420 + 13, 480 + 5, 570 + 5 for
-//            2, 4, 8 waves (what a launch of a few targets takes per site).
-// The constants are fits (3.6 % rms on the issue side) to 240 launches on MI355X: N = 1000 ... 5100, K = N / 16
-// ... N, 1 to 8 waves per target.  What the rule does not see is the number of rounds and the fill: N = K = 3000
-// is 2.93 rounds of 2 x 24 words (20.8 ms) but 1.95 rounds of 1 x 48 (16.2 ms); 375 of those targets take
-// 4.7 ms as 2 x 24 and 3.6 ms as 4 x 12.  Over the measured launches the rule is 6.7 % (geometric mean) behind
-// the best wave count, the model's choice 0.8 %, and at most 4 % behind the rule's (N = K = 2300, one theta:
-// 15.0 ms as 1 x 36 against 14.4; with two thetas 16.8 against 18.3).
+//   latency: the dependent chain of one site, 187 + 14.8 ns per word for one wave, 227 + 20.6, 359 + 6.8, 460 + 8.8
+//            for 2, 4, 8 waves (what a launch of a few targets takes per site).
+// A last round that is not full runs at the occupancy its waves reach, but never under 0.86 of a full round: its
+// waves start beside the last ones of the round before and share their SIMDs with them.
+// The exchange, latency and last-round constants are fits to 240 launches of the present kernels on MI355X
+// (N = 1000 ... 5008, K = N / 16 ... N, every wave count; tools/geometry_sweep_k.py), the issue slots to those of the
+// first kernels.  What the size rule does not see is the number of rounds and the fill: N = K = 3000 is 2.93
+// rounds of 2 x 24 words (17.2 ms) but 1.95 rounds of 1 x 48 (15.5 ms); 375 of those targets take 4.2 ms as 2 x 24
+// and 3.2 ms as 4 x 12.  Over the measured launches the rule is 7.9 % (geometric mean) behind the best wave count,
+// the model's choice 0.5 % (worst: 13.6 % at N = 2000, K = 500), and it is the best count for every K = N.
 namespace {
 
 // Waves of the kernel that a CU holds: 512 VGPRs per SIMD for 56 + 2 MPL registers per lane, and 160 KiB of LDS,
@@ -669,12 +672,12 @@ int waves_per_cu(PaintGeometry g)
 double round_cost(PaintGeometry g, int occ)
 {
   static const double ns_per_slot[9] = {0.0, 4.0, 3.45, 2.73, 2.24, 2.09, 1.89, 1.89, 1.89};
-  const double exchange = g.G == 1 ? 0.0 : g.G == 2 ? 29.0 : g.G == 4 ? 20.0 : 49.0;
+  const double exchange = g.G == 1 ? 0.0 : g.G == 2 ? 10.0 : g.G == 4 ? 14.0 : 21.0;
   const double issue = occ * (3.0 * g.MPL + 24.0 + exchange) * ns_per_slot[occ];
-  const double latency = g.G == 1   ? 300.0 + 10.5 * g.MPL
-                         : g.G == 2 ? 420.0 + 13.0 * g.MPL
-                         : g.G == 4 ? 480.0 + 5.0 * g.MPL
-                                    : 570.0 + 5.0 * g.MPL;
+  const double latency = g.G == 1   ? 187.0 + 14.8 * g.MPL
+                         : g.G == 2 ? 227.0 + 20.6 * g.MPL
+                         : g.G == 4 ? 359.0 + 6.8 * g.MPL
+                                    : 460.0 + 8.8 * g.MPL;
   return std::max(issue, latency);
 }
 
@@ -687,11 +690,13 @@ double launch_cost(PaintGeometry g, int K)
   const int occ = (int)std::max(1LL, std::min<long long>((cu + 3) / 4, (waves + 767) / 768));
   const long long slots = std::min(256LL * cu, 1024LL * occ);
   const long long rounds = (waves + slots - 1) / slots;
-  // the last round runs at the occupancy its waves reach (N = K = 2100 as 1 x 36: 8.25 ms for the full round,
-  // 4.7 ms for the 52 targets of the second)
+  // the last round runs at the occupancy its waves reach, beside the end of the round before (N = K = 2100 as
+  // 1 x 36: 13.4 ms, of which the 52 targets of the second round take 5)
   const long long rest = waves - (rounds - 1) * slots;
   const int occ_last = (int)std::max(1LL, std::min<long long>(occ, (rest + 767) / 768));
-  return (double)(rounds - 1) * round_cost(g, occ) + round_cost(g, occ_last);
+  double last = round_cost(g, occ_last);
+  if (rounds > 1) last = std::max(last, 0.86 * round_cost(g, occ));
+  return (double)(rounds - 1) * round_cost(g, occ) + last;
 }
 
 }  // namespace
@@ -702,7 +707,7 @@ PaintGeometry choose_geometry_for_launch(int N, int K, int prefer_waves, int var
   if (variant < 1 || prefer_waves != 0 || rule.MPL <= 0 || K <= 0) return rule;
   if (N > 5120) return rule;  // beyond the sizes the constants were fitted on
   PaintGeometry best = rule;
-  double best_cost = 0.93 * launch_cost(rule, K);
+  double best_cost = launch_cost(rule, K);
   for (int G = 1; G <= 8; G *= 2) {
     const PaintGeometry g = choose_geometry(N, G, variant);  // a nonzero wave count is taken as given
     if (g.MPL <= 0 || g.G != G) continue;

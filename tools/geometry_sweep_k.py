@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Times launches of K < N targets (paint stage only) for every wave count per target.
 
-Usage: geometry_sweep_k.py OUT N1,N2,... ; one line per (N, K, waves asked): geometry used, ms."""
+Usage: geometry_sweep_k.py OUT N1,N2,... [W1,W2,...] ; one line per (N, K, waves asked): geometry used, ms.
+Wave counts default to 0,1,2,4,8 (0 = the automatic choice)."""
 import os
 import sys
 
@@ -13,6 +14,7 @@ import relate_amd as ra
 
 out = sys.argv[1]
 sizes = [int(x) for x in sys.argv[2].split(",")]
+wave_counts = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1, 2, 4, 8]
 L = 50000
 with open(out, "a") as f:
     for N in sizes:
@@ -22,7 +24,7 @@ with open(out, "a") as f:
         d_out = torch.empty((len(wb) - 1) * N * ra.record_bytes(N), dtype=torch.uint8, device="cuda")
         stream = torch.cuda.current_stream().cuda_stream
         for K in (N, N // 2, N // 4, N // 8, N // 16):
-            for waves in (0, 1, 2, 4, 8):
+            for waves in wave_counts:
                 plan = ra.Plan(0, 1, waves)
                 plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, stream)
                 ms = []
