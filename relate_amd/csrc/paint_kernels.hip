@@ -290,16 +290,34 @@ __global__ void __launch_bounds__(256) site_terms_kernel(const int32_t* __restri
   const long long o = off[t];
   // the 24-byte records of a block are contiguous: they go through LDS and leave as coalesced 8-byte stores
   __shared__ double staged[256 * 3];
+  // list entries j-2 .. j+2 of the block's sites, indices clamped to the list: one coalesced load for all of them
+  // (fetched by each thread for itself they were three dependent round trips to memory per block)
+  __shared__ int32_t entries[256 + 4];
   static_assert(sizeof(SiteRec) == 24, "three 8-byte words per record");
   for (int jb = blockIdx.x * blockDim.x; jb < n; jb += gridDim.x * blockDim.x) {
+    for (int i = threadIdx.x; i < (int)blockDim.x + 4; i += blockDim.x) {
+      int q = jb - 2 + i;
+      q = q < 0 ? 0 : (q > n - 1 ? n - 1 : q);
+      entries[i] = dk[o + q];
+    }
+    __syncthreads();
     const int j = jb + threadIdx.x;
     if (j < n) {
-      const int s0 = dk[o + j];
-      const int s1 = (j + 1 < n) ? dk[o + j + 1] : s0 + 1;
-      // left to right as the reference adds them; the loads of 8 terms go out together (one round trip
-      // instead of eight: the gaps of a wave's lanes differ, and the longest sets its pace)
+      const int s0 = entries[threadIdx.x + 2];
+      const int s1 = (j + 1 < n) ? entries[threadIdx.x + 3] : s0 + 1;
+      // left to right as the reference adds them; the loads of the first 9 terms (then of 8 at a time) go out
+      // together: one round trip instead of one per term (the gaps of a wave's lanes differ, and the longest sets
+      // its pace)
       double rsum = r[s0];
-      for (int s = s0 + 1; s < s1; s += 8) {
+      {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (s0 + 1 + u < s1) ? r[s0 + 1 + u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (s0 + 1 + u < s1) rsum += v[u];
+      }
+      for (int s = s0 + 9; s < s1; s += 8) {
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = (s + u < s1) ? r[s + u] : 0.0;
@@ -319,15 +337,15 @@ __global__ void __launch_bounds__(256) site_terms_kernel(const int32_t* __restri
         nx[o + j] = nxv;
       }
       if (rec) {
-        const int f2 = dk[o + (j + 2 < n ? j + 2 : n - 1)];
-        const int b2 = dk[o + (j > 1 ? j - 2 : 0)];
+        const int f2 = entries[threadIdx.x + 4];  // dk[min(j + 2, n - 1)]
+        const int b2 = entries[threadIdx.x];      // dk[max(j - 2, 0)]
         staged[3 * threadIdx.x] = cf;
         staged[3 * threadIdx.x + 1] = nxv;
         staged[3 * threadIdx.x + 2] = __hiloint2double(b2, f2);  // dk_fwd2 in the low word, dk_bwd2 in the high word
       }
     }
+    __syncthreads();  // (also: every thread is done with `entries` before the next block of sites overwrites them)
     if (rec) {
-      __syncthreads();
       const int cnt = 3 * (n - jb < (int)blockDim.x ? n - jb : (int)blockDim.x);
       double* dst = reinterpret_cast<double*>(rec + o + jb);
       for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = staged[i];
