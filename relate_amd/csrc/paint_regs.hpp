@@ -910,7 +910,6 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
   // the pair 2i, 2i+1 takes which pass follows the parity of the set bits of the block index, so that
   // every power-of-two stride of the dispatcher (XCDs, CUs, SIMDs) sees both kinds.
   const int pass = __builtin_popcount(blockIdx.x) & 1;
-  const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();
   // slot of this wave on its SIMD (HW_ID.wave_id); the waves of a multi-wave workgroup meet at a barrier
   // every site and must share one schedule, so they take it from the block index instead
   const int rank = G == 1 ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 3) : (int)((blockIdx.x >> 1) & 3);
@@ -927,6 +926,8 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
   const int kw = k >> 6, kb = k & 63;
   const bool first_thread = threadIdx.x == 0;
   const uint64_t* rows_w = ka.rows + wbase;  // the words of this wave start here in every row
+  // diagnostics: the start time goes out now, so that no loop carries it (finish() writes the rest)
+  if (ka.trace && first_thread) ka.trace[(size_t)4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 
   // Lanes without a state: the target's own (its bit, or 0 if its word belongs to another wave) and the
   // padding lanes from the first incomplete word of this wave on; into their fixed registers.
@@ -960,15 +961,16 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
 
   // Diagnostics at the end of a pass.  Each pass ends with its own call and returns: code shared after the
   // three branches would let the compiler move the set-up loads of a later branch into the loop of an earlier one.
+  // What it writes is fetched again here (the list length) or computed again (the pass): a value kept for it
+  // through the loops costs them a register, and a spilled one a vector instruction per site to bring it back.
   auto finish = [&]() __attribute__((always_inline)) {
     KArgsPtr q = rare_args();
     if (q->trace && threadIdx.x == 0) {
       uint64_t* tr = q->trace + (size_t)4 * blockIdx.x;
       const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
       tr[0] = ((uint64_t)xcc << 32) | hw;
-      tr[1] = trace_t0;
       tr[2] = __builtin_amdgcn_s_memrealtime();
-      tr[3] = (uint64_t)pass | ((uint64_t)nd << 8);
+      tr[3] = (uint64_t)(__builtin_popcount(blockIdx.x) & 1) | ((uint64_t)q->nd_all[q->order[blockIdx.x >> 1]] << 8);
     }
   };
 

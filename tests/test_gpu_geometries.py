@@ -51,3 +51,25 @@ def test_automatic_choice_counts_rounds():
     want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb, 0, N)
     got = gpu_paint(seq, r, 0.001, 0.001, wb, 1, 0, 0, N)
     assert compare_records(got, want, N, "N=3000, all targets, automatic geometry") == 0.0
+
+
+def test_trace_of_a_launch(tmp_path, monkeypatch):
+    """RELATE_TRACE=<file>: per workgroup of the recursion kernel 4 x u64 -- where it ran, start and end in 100 MHz
+    ticks, pass | list length << 8.  The start is written when the workgroup begins and the rest when it ends;
+    both passes of every target are there, each with the target's number of sites."""
+    import numpy as np
+    N, L, W = 300, 400, 3
+    seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=37, r_mode="flat")
+    path = tmp_path / "trace.bin"
+    monkeypatch.setenv("RELATE_TRACE", str(path))
+    want = ol.oracle().paint_stones(seq, r, 0.001, 0.001, wb, 0, N)
+    got = gpu_paint(seq, r, 0.001, 0.001, wb, 1, 0, 0, N)
+    assert compare_records(got, want, N, "traced launch") == 0.0
+    tr = np.fromfile(path, dtype=np.uint64).reshape(2 * N, 4)
+    assert np.all(tr[:, 1] > 0) and np.all(tr[:, 2] >= tr[:, 1]), "start and end times of every workgroup"
+    passes = (tr[:, 3] & np.uint64(0xFF)).astype(np.int64)
+    nd = (tr[:, 3] >> np.uint64(8)).astype(np.int64)
+    assert sorted(passes.tolist()) == [0] * N + [1] * N
+    der = seq == ord("1")
+    want_nd = der.sum(axis=0) + (~der[0]).astype(np.int64) + (~der[-1]).astype(np.int64)  # sites 0 and L-1 are always listed
+    assert sorted(nd[passes == 0].tolist()) == sorted(want_nd.tolist()) == sorted(nd[passes == 1].tolist())
