@@ -932,7 +932,9 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
   // Lanes without a state: the target's own (its bit, or 0 if its word belongs to another wave) and the
   // padding lanes from the first incomplete word of this wave on; into their fixed registers.
   auto stateless = [&]() __attribute__((always_inline)) {
-    const int N = ka.p.N;
+    // (through the opaque pointer: read from `ka`, the compiler may fetch the word at the latch of the site loop
+    // that follows, with a wait for it at every site)
+    const int N = rare_args()->p.N;
     const int full_words = N >> 6, rem = N & 63;
     const bool self_here = kw >= wbase && kw < wbase + MPL;
     const int w_ph = full_words > wbase ? full_words : wbase;

@@ -62,3 +62,36 @@ def test_checker_reads_the_limits_a_kernel_states(tmp_path):
     for f, what in ((bad_a, "a40"), (bad_s, "s44")):
         p = run(f)
         assert p.returncode == 1 and what in p.stderr
+
+
+def test_checker_flags_a_scalar_load_at_a_loop_latch(tmp_path):
+    """A compiler scalar load in a block that falls through into a loop header runs at every site and waits for the
+    row fetch in flight; the same load in a conditional block of the loop body (a rare path) is fine."""
+    head = "_ZN6relate4regs14paint_kernel_rILi20ELi4EEEvNS0_5KArgsE:\n"
+    loop = (".LBB4_68:                               ; =>This Loop Header: Depth=1\n"
+            "\ts_and_b32 s0, s33, 31\n"
+            "\ts_cbranch_scc1 .LBB4_80\n"
+            "; %%bb.69:\n"
+            ".LBB4_70:                               ; %%rare\n"
+            "                                        ;   in Loop: Header=BB4_68 Depth=1\n"
+            "%s"
+            "\ts_branch .LBB4_67\n"
+            ".LBB4_80:\n"
+            "                                        ;   in Loop: Header=BB4_68 Depth=1\n"
+            "\ts_nop 0\n")
+    latch = (".LBB4_67:                               ; %%Flow\n"
+             "                                        ;   in Loop: Header=BB4_68 Depth=1\n"
+             "%s"
+             "\ts_add_i32 s0, s33, -1\n"
+             "\ts_cbranch_scc1 .LBB4_104\n")
+    load = "\ts_load_dwordx4 s[20:23], s[34:35], 0x58\n"
+    tail = ".LBB4_104:\n\t.end_amdhsa_kernel\n"
+    ok, bad = tmp_path / "ok.s", tmp_path / "bad.s"
+    # (the latch precedes the header in the file, as the compiler lays the loop out)
+    ok.write_text(head + latch % "" + loop % load + tail)
+    bad.write_text(head + latch % load + loop % "" + tail)
+    run = lambda f: subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_regs.py"), str(f)],  # noqa: E731
+                                   capture_output=True, text=True)
+    assert run(ok).returncode == 0, run(ok).stderr
+    p = run(bad)
+    assert p.returncode == 1 and "loop latch" in p.stderr and "0x58" in p.stderr

@@ -7,6 +7,11 @@ v24+ / s24+), and rely on the compiler staying below those limits.  This script 
 assembly (hipcc -S --cuda-device-only) of the instantiation files and fails if any instruction the
 COMPILER emitted (i.e. outside the asm statements) inside a paint_kernel_r / repaint_kernel_r kernel names v48+ or s52+.
 
+It also fails if the compiler put a scalar load of its own into the latch of a loop (a block inside a loop that falls
+through into the loop's header): such a load runs at every site and brings a wait for all scalar loads with it,
+the row fetch in flight included (measured: 1.2 % of the 5008-haplotype launch for one reloaded kernel argument).
+Loads in the rare paths of a loop body (stones, rescales) sit in conditional blocks and are not meant.
+
     python tools/check_regs.py relate_amd/csrc/paint_regs_g1.s ...
 """
 import re
@@ -22,6 +27,7 @@ def check(path):
     kernel = None
     in_asm = False
     counts = {}
+    block_loads, block_in_loop, after_label = [], False, False
     for ln, line in enumerate(open(path), 1):
         m = re.match(r"^(_ZN6relate\d+(regs|aloop)\d+(?:paint|repaint|repaint_fwd|repaint_bwd)_kernel_[ra]\w+):", line)
         if m:
@@ -33,7 +39,16 @@ def check(path):
         if line.startswith("\t.end_amdhsa_kernel") or ".Lfunc_end" in line:
             kernel = None
         if kernel is None:
+            block_loads, block_in_loop, after_label = [], False, False
             continue
+        if line.startswith(".LBB"):
+            if block_loads and block_in_loop and "Loop Header" in line:
+                bad += [f"{path}:{n}: {kernel[:60]}: scalar load at a loop latch: {c}" for n, c in block_loads]
+            block_loads, block_in_loop, after_label = [], False, True
+            continue
+        if after_label:
+            block_in_loop = "in Loop: Header=" in line
+            after_label = False
         if "#ASMSTART" in line:
             in_asm = True
             continue
@@ -52,6 +67,8 @@ def check(path):
         if in_asm or not code.strip() or code.lstrip().startswith("."):
             continue
         counts[kernel] += 1
+        if re.match(r"\s+s_load_dword", code):
+            block_loads.append((ln, code.strip()))
         for r in REG.finditer(code):
             if r.group(1):
                 cls, hi = r.group(1), int(r.group(2))
@@ -75,7 +92,7 @@ def main():
         return 2
     if total_bad:
         print("\n".join(total_bad[:40]), file=sys.stderr)
-        print(f"check_regs: {len(total_bad)} compiler instructions touch reserved registers", file=sys.stderr)
+        print(f"check_regs: {len(total_bad)} compiler instructions touch reserved registers or load at a loop latch", file=sys.stderr)
         return 1
     print(f"check_regs: {nk} kernels clean")
     return 0
