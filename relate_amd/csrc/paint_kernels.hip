@@ -279,6 +279,14 @@ __global__ void __launch_bounds__(256) fill_sites_kernel(const uint64_t* __restr
 // gap j is accumulated left to right starting from r[dk[j]]; the last entry is
 // r[L-1] alone.  Stored as coef = r_prob/((1-r_prob)(N-1)), the only form the
 // recursion uses (:274,:365,:469,:569), and nor_x_theta.
+//
+// Two phases per block of 1024 sites.  Summing: a thread walks the SNPs of kSitesPerThread consecutive sites,
+// whose gaps are one contiguous run of r, and drops each sum into LDS when the run crosses into the next site.
+// The gaps of a panel of thousands are a few SNPs on average and tens at the longest, and a wave moves at the
+// pace of its longest lane: over four gaps per lane the longest lane is about twice the mean, over one gap
+// four to five times.  Then one site per thread again for exp, division and the record.
+constexpr int kSitesPerThread = 4;
+constexpr int kSitesPerBlock = 256 * kSitesPerThread;
 __global__ void __launch_bounds__(256) site_terms_kernel(const int32_t* __restrict__ dk, const int64_t* __restrict__ off,
                                                          const int32_t* __restrict__ nd, const double* __restrict__ r,
                                                          double log_ntheta, double log_small, double Nm1,
@@ -288,67 +296,84 @@ __global__ void __launch_bounds__(256) site_terms_kernel(const int32_t* __restri
   const int t = blockIdx.y;
   const int n = nd[t];
   const long long o = off[t];
+  constexpr int T = kSitesPerThread, BS = kSitesPerBlock;
   // the 24-byte records of a block are contiguous: they go through LDS and leave as coalesced 8-byte stores
-  __shared__ double staged[256 * 3];
+  __shared__ double staged[BS * 3];
   // list entries j-2 .. j+2 of the block's sites, indices clamped to the list: one coalesced load for all of them
-  // (fetched by each thread for itself they were three dependent round trips to memory per block)
-  __shared__ int32_t entries[256 + 4];
+  __shared__ int32_t entries[BS + 4];
+  __shared__ double gap_sum[BS];
   static_assert(sizeof(SiteRec) == 24, "three 8-byte words per record");
-  for (int jb = blockIdx.x * blockDim.x; jb < n; jb += gridDim.x * blockDim.x) {
-    for (int i = threadIdx.x; i < (int)blockDim.x + 4; i += blockDim.x) {
+  for (int jb = blockIdx.x * BS; jb < n; jb += gridDim.x * BS) {
+    for (int i = threadIdx.x; i < BS + 4; i += blockDim.x) {
       int q = jb - 2 + i;
       q = q < 0 ? 0 : (q > n - 1 ? n - 1 : q);
       entries[i] = dk[o + q];
     }
     __syncthreads();
-    const int j = jb + threadIdx.x;
-    if (j < n) {
-      const int s0 = entries[threadIdx.x + 2];
-      const int s1 = (j + 1 < n) ? entries[threadIdx.x + 3] : s0 + 1;
-      // left to right as the reference adds them; the loads of the first 9 terms (then of 8 at a time) go out
-      // together: one round trip instead of one per term (the gaps of a wave's lanes differ, and the longest sets
-      // its pace)
-      double rsum = r[s0];
-      {
+    // ---- sums of the gaps of sites j0 .. j0 + cnt - 1, left to right as the reference adds them (:84-96) ----
+    const int j0 = jb + (int)threadIdx.x * T;
+    if (j0 < n) {
+      const int cnt = n - j0 < T ? n - j0 : T;
+      const int e0 = (int)threadIdx.x * T + 2;  // entries[e0 + i] = first SNP of site j0 + i
+      // one past the last SNP of site j0 + i: the next site's first, or for the last site of the list its own + 1
+      auto gap_end = [&](int i) { return j0 + i + 1 < n ? entries[e0 + i + 1] : entries[e0 + i] + 1; };
+      const int s_first = entries[e0];
+      const int s_stop = gap_end(cnt - 1);
+      int site = 0, end = gap_end(0);
+      double rsum = r[s_first];
+      // the loads of 8 terms go out together: one round trip to memory instead of eight
+      for (int s = s_first + 1; s < s_stop; s += 8) {
         double v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = (s0 + 1 + u < s1) ? r[s0 + 1 + u] : 0.0;
+        for (int u = 0; u < 8; u++) v[u] = (s + u < s_stop) ? r[s + u] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (s0 + 1 + u < s1) rsum += v[u];
+        for (int u = 0; u < 8; u++) {
+          if (s + u < s_stop) {
+            if (s + u == end) {  // the run crosses into the next site: its sum starts with this term
+              gap_sum[threadIdx.x * T + site] = rsum;
+              site++;
+              end = gap_end(site);
+              rsum = v[u];
+            } else {
+              rsum += v[u];
+            }
+          }
+        }
       }
-      for (int s = s0 + 9; s < s1; s += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = (s + u < s1) ? r[s + u] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (s + u < s1) rsum += v[u];
-      }
-      double nxv = -rsum + log_ntheta;
-      double rp = 1.0 - exp(-rsum);
-      if (rp > 0.99) {
-        rp = 0.99;
-        nxv = log_small + log_ntheta;
-      }
-      const double cf = rp / ((1.0 - rp) * Nm1);
-      if (coef) {
-        coef[o + j] = cf;
-        nx[o + j] = nxv;
-      }
-      if (rec) {
-        const int f2 = entries[threadIdx.x + 4];  // dk[min(j + 2, n - 1)]
-        const int b2 = entries[threadIdx.x];      // dk[max(j - 2, 0)]
-        staged[3 * threadIdx.x] = cf;
-        staged[3 * threadIdx.x + 1] = nxv;
-        staged[3 * threadIdx.x + 2] = __hiloint2double(b2, f2);  // dk_fwd2 in the low word, dk_bwd2 in the high word
+      gap_sum[threadIdx.x * T + site] = rsum;  // (site == cnt - 1: the loop has passed the first SNP of every later site)
+    }
+    __syncthreads();
+    // ---- one site per thread: the terms and the record ----
+    for (int k = 0; k < T; k++) {
+      const int jl = k * (int)blockDim.x + (int)threadIdx.x;
+      const int j = jb + jl;
+      if (j < n) {
+        const double rsum = gap_sum[jl];
+        double nxv = -rsum + log_ntheta;
+        double rp = 1.0 - exp(-rsum);
+        if (rp > 0.99) {
+          rp = 0.99;
+          nxv = log_small + log_ntheta;
+        }
+        const double cf = rp / ((1.0 - rp) * Nm1);
+        if (coef) {
+          coef[o + j] = cf;
+          nx[o + j] = nxv;
+        }
+        if (rec) {
+          const int f2 = entries[jl + 4];  // dk[min(j + 2, n - 1)]
+          const int b2 = entries[jl];      // dk[max(j - 2, 0)]
+          staged[3 * jl] = cf;
+          staged[3 * jl + 1] = nxv;
+          staged[3 * jl + 2] = __hiloint2double(b2, f2);  // dk_fwd2 in the low word, dk_bwd2 in the high word
+        }
       }
     }
-    __syncthreads();  // (also: every thread is done with `entries` before the next block of sites overwrites them)
+    __syncthreads();  // (also: every thread is done with `entries` and `gap_sum` before the next block of sites)
     if (rec) {
-      const int cnt = 3 * (n - jb < (int)blockDim.x ? n - jb : (int)blockDim.x);
+      const int cnt3 = 3 * (n - jb < BS ? n - jb : BS);
       double* dst = reinterpret_cast<double*>(rec + o + jb);
-      for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = staged[i];
+      for (int i = threadIdx.x; i < cnt3; i += blockDim.x) dst[i] = staged[i];
       __syncthreads();
     }
   }
@@ -781,7 +806,7 @@ hipError_t launch_site_terms(const int32_t* d_dk, const int64_t* d_off, const in
                              SiteRec* d_rec, hipStream_t st)
 {
   (void)L;
-  int bx = (max_nd + 255) / 256;
+  int bx = (max_nd + kSitesPerBlock - 1) / kSitesPerBlock;
   if (bx > 64) bx = 64;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(site_terms_kernel, dim3(bx, K), dim3(256), 0, st, d_dk, d_off, d_nd, d_r, c.log_ntheta,
