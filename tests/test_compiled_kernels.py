@@ -70,13 +70,15 @@ def test_several_waves_and_several_rounds(N, G, MPL, tp, td):
 
 @pytest.mark.parametrize("N,L,G,MPL,k0,theta,mode", [(130, 400, 1, 4, 127, 0.025, "skew"), (600, 300, 2, 8, 62, 0.001, "flat"),
                                                      (1100, 200, 1, 20, 0, 0.001, "skew"), (2000, 300, 2, 16, 1998, 0.001, "flat"),
-                                                     (4900, 200, 4, 20, 0, 0.001, "skew")])
+                                                     (4900, 200, 4, 20, 0, 0.001, "skew"),
+                                                     (2040, 200, 1, 32, 2038, 0.001, "flat")])  # 32 words per lane: every alpha row a checkpoint
 def test_repainting_kernels_from_checkpoints(N, L, G, MPL, k0, theta, mode):
     """repaint_fwd_kernel_r / repaint_bwd_kernel_r as compiled: the forward launch keeps every B-th alpha row, the
     backward launch recomputes the others into accumulation registers (the interpreter keeps them apart from the
     compiler's own and checks every access); topology rows and logscales against the re-painting oracle bit for bit.
     Geometries of the benchmark's windows among them (2 x 16 words: N = 2000; 4 x 20: N = 5008), several blocks per
-    section, rescales inside sections (skewed map)."""
+    section, rescales inside sections (skewed map), and one geometry of 32 words per lane, where there is no room for
+    slots and every alpha row is a checkpoint."""
     import emu_kernel as ek
     K = 2
     seq, r, wb = sy.make_chunk(N=N, L=L, W=2, seed=N, r_mode=mode)
@@ -95,7 +97,8 @@ def test_repainting_kernels_from_checkpoints(N, L, G, MPL, k0, theta, mode):
             assert np.array_equal(got_ls.view(np.uint32), want_ls.view(np.uint32))
             assert np.all(got_top[:, N:] == 0)
             blocks = max(blocks, -(-len(want_top) // ek.repaint_block_rows(MPL)))
-    assert ek.repaint_block_rows(MPL) > 1 and blocks > 1
+    assert blocks > 1, "sections of several blocks"
+    assert (ek.repaint_block_rows(MPL) == 1) == (MPL >= 32), "the one case of 32 words per lane keeps every row"
 
 
 # ---- the plain kernels (paint_kernels.s) ------------------------------------------------------------------------

@@ -50,8 +50,9 @@ def bookkeeping_fast(seq, rpos, snp, a_snp, off):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("N,L,tag", [(2000, 50000, "c2"), (5008, 100000, "c3")])
-def test_one_window_repainted_and_measured(N, L, tag):
+@pytest.mark.parametrize("N,L,tag,waves", [(2000, 50000, "c2", 0), (5008, 100000, "c3", 0),
+                                           (2000, 50000, "c2, one wave of 32 words per target: every alpha row a checkpoint", 1)])
+def test_one_window_repainted_and_measured(N, L, tag, waves):
     import torch
     import relate_amd as ra
     theta = 0.001
@@ -62,13 +63,15 @@ def test_one_window_repainted_and_measured(N, L, tag):
     d_seq = torch.from_numpy(seq).cuda()
     d_r = torch.from_numpy(r).cuda()
     stones = torch.empty(W * N * R, dtype=torch.uint8, device="cuda")
-    plan = ra.Plan(0)
+    plan = ra.Plan(0, 1, waves)
     st = torch.cuda.current_stream().cuda_stream
     plan.load_device(N, L, d_seq.data_ptr(), d_r.data_ptr(), wb, st)
     plan.prepare(theta, theta, 0, N, st)
     plan.paint(stones.data_ptr(), st)
     torch.cuda.synchronize()  # (d_r stays alive: the plan borrows it, and re-painting reads it again)
     w = W // 2
+    if waves == 1:
+        assert plan.repaint_geometry()["checkpoint_rows"] == 1
     rows, pitch, off = plan.repaint_layout(w)
     top = torch.full((rows, pitch), float("nan"), dtype=torch.float32, device="cuda")
     ls = torch.full((rows,), float("nan"), dtype=torch.float32, device="cuda")
