@@ -246,6 +246,17 @@ __device__ __forceinline__ BlockSeeds load_block_seeds(const int32_t* p_prev, co
   return r;
 }
 
+// S < lo || S > hi with the thresholds fetched where they are needed (rare: see surely_in_range); the loops of
+// several waves per target use this, because their exchange passes through the registers that hold the thresholds
+// for out_of_range().
+typedef const __attribute__((address_space(4))) RepaintKArgs* RepaintKArgsPtr;
+__device__ __forceinline__ bool repaint_out_of_range_exact(double S)
+{
+  RepaintKArgsPtr q = (RepaintKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  return __builtin_amdgcn_ballot_w64(S < q->p.c.lo || S > q->p.c.hi) != 0;  // S is the same in every lane
+}
+
 template <int I>
 __device__ __forceinline__ double state_get()
 {
@@ -330,20 +341,53 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
   // backward launch's second run over a block: the same instructions in the same order, so that both produce the
   // same doubles.  Returns true when the row was rescaled (lg = log of the sum it was divided by).
   // Scalars that travel: coef_j (gap before this site), the running record pointer, s_next (site after this one).
-  auto forward_site = [&](int j, double& S, double& coef_j, double& nx_j, const uint64_t*& rp, int& s_next, double rho_l,
-                          int stride_l, double& lg) __attribute__((always_inline)) -> bool {
-    const double rx = S * coef_j;
-    write_stateless<MPL, false>(S, coef_j);
-    prefetch_site<true>();
-    const uint64_t skm = edge_select(j, nds - 1, sk_last);
-    double c0, c1;
-    const uint64_t* rp_next = rows_w + (size_t)s_next * stride_l;
-    sweep_row<MPL>(c0, c1, rx, rho_l, skm, rp, rp_next);
-    S = block_sum_regs<G>(red, slot, c0, c1);
-    int s_next2;
-    fetched_site<true>(s_next2, coef_j, nx_j);
+  //
+  // Several waves per target (G > 1) run the site as the recursion kernel's loops of several waves do
+  // (paint_regs.hpp): the gap terms and the list entry of the site after the next are used in the scalar registers
+  // where their fetch leaves them (set_site_terms before the first site; the fetch itself travels with the next
+  // site's row words), the block sum goes through exchange_sum (`step` = j; a barrier before the first site of a run
+  // and after its last, where the entries change hands with block_sum_hi), the range check is the scalar one, and a
+  // wave without lanes to reset skips that step.  Then coef_j, nx_j and s_next are not used; rp_nx is the row of
+  // the site after this one.
+  uint32_t wr_addr = 0, rd_base = 0;
+  uint32_t stride_bytes = 8u * (uint32_t)stride;
+  if constexpr (G > 1) {
+    exchange_addresses<G>(red, wr_addr, rd_base);
+    set_rows_base(rows_w);
+    asm volatile("" : "+s"(stride_bytes));
+  }
+  auto forward_site = [&](int j, double& S, double& coef_j, double& nx_j, const uint64_t*& rp, const uint64_t*& rp_nx, int& s_next,
+                          double rho_l, int stride_l, double& lg) __attribute__((always_inline)) -> bool {
+    bool out_of_band;
+    if constexpr (G == 1) {
+      const double rx = S * coef_j;
+      write_stateless<MPL, false>(S, coef_j);
+      prefetch_site<true>();
+      const uint64_t skm = edge_select(j, nds - 1, sk_last);
+      double c0, c1;
+      const uint64_t* rp_next = rows_w + (size_t)s_next * stride_l;
+      sweep_row<MPL>(c0, c1, rx, rho_l, skm, rp, rp_next);
+      S = block_sum_regs<G>(red, slot, c0, c1);
+      int s_next2;
+      fetched_site<true>(s_next2, coef_j, nx_j);
+      out_of_band = out_of_range(S);
+      s_next = s_next2;
+      rp = rp_next;
+    } else {
+      const double rx = times_site_coef(S);
+      write_stateless_site<MPL>(S);
+      const uint64_t skm = edge_select(j, nds - 1, sk_last);
+      double c0, c1;
+      sweep_row<MPL, 1>(c0, c1, rx, rho_l, skm, rp, rp_nx);
+      S = exchange_sum<G>(wr_addr, rd_base, j, c0, c1);
+      const uint32_t S_high = sgpr32((uint32_t)__double2hiint(S));
+      const uint64_t* rp_nx2 = fetched_row_pointer<true>(stride_bytes);
+      out_of_band = !surely_in_range(S_high) && repaint_out_of_range_exact(S);
+      rp = rp_nx;
+      rp_nx = rp_nx2;
+    }
     bool rescaled = false;
-    if (out_of_range(S)) {
+    if (out_of_band) {
       const double inv = 1.0 / S;
       static_for<0, MPL>([&](auto ic) __attribute__((always_inline)) {
         const double f = inv;
@@ -353,8 +397,6 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
       S = 1.0;
       rescaled = true;
     }
-    s_next = s_next2;
-    rp = rp_next;
     return rescaled;
   };
 
@@ -395,13 +437,20 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
     double rho_l = rho;
     asm volatile("" : "+v"(rho_l));
     const uint64_t* rp = rows_w + (size_t)s_cur * stride_l;
+    const uint64_t* rp_nx = rows_w + (size_t)s_next * stride_l;
     sload_round<0, RowRounds<MPL>::size(0)>(rp);
+    if constexpr (G > 1) {
+      set_site_terms(sgpr_f64(coef_j), sgpr_f64(nx_j));
+      __syncthreads();  // every wave has read the entries of the sum above
+    }
     for (int j = 1; j < nds; j++) {
       if ((j & 31) == 0) rotate_priority(rank, j, 0);
-      prev += nx_j;  // the gap before site j (nx_j is replaced by the next gap's inside forward_site)
+      // the gap before site j (the terms are replaced by the next gap's inside forward_site)
+      if constexpr (G == 1) prev += nx_j;
+      else add_site_nx(prev);
       float lsj = (float)prev;  // (:839-841) the float is what the rescale term is added to
       double lg;
-      if (forward_site(j, S, coef_j, nx_j, rp, s_next, rho_l, stride_l, lg)) {
+      if (forward_site(j, S, coef_j, nx_j, rp, rp_nx, s_next, rho_l, stride_l, lg)) {
         prev += lg;
         lsj = (float)((double)lsj + lg);
       }
@@ -504,13 +553,19 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
           double coef_j = seeds.coef_f, nx_j = seeds.nx_f;
           set_site_pointer(rec_s + r0 + 1);
           const uint64_t* rp = rows_w + (size_t)s_cur * stride_l;
+          const uint64_t* rp_nx = rows_w + (size_t)s_next * stride_l;
           sload_round<0, RowRounds<MPL>::size(0)>(rp);
+          if constexpr (G > 1) {
+            set_site_terms(sgpr_f64(coef_j), sgpr_f64(nx_j));
+            __syncthreads();  // the entries of the block sums pass from block_sum_hi to exchange_sum
+          }
           for (int i = 1; r0 + i < r1; i++) {
             double lg;
-            forward_site(r0 + i, S, coef_j, nx_j, rp, s_next, rho_l, stride_l, lg);
+            forward_site(r0 + i, S, coef_j, nx_j, rp, rp_nx, s_next, rho_l, stride_l, lg);
             slot_save_at<MPL, B - 1>(i - 1);
           }
           swait();  // the row words asked for beyond the block: the registers go to the backward sweeps next
+          if constexpr (G > 1) __syncthreads();  // ... and back
         }
       }
       if (c == nblk - 1) {
@@ -570,7 +625,10 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
           else if (j == r0) parked_product<MPL>(park_addr, as_global(top_rows + (size_t)j * pitch_l), col4);
           else slot_product_at<MPL, B - 1>(j - r0 - 1, as_global(top_rows + (size_t)j * pitch_l), col4);
           float lsj = (float)((double)ls_fwd + prev);  // (:994-997)
-          if (out_of_range(Bs)) {
+          bool out_of_band;
+          if constexpr (G == 1) out_of_band = out_of_range(Bs);
+          else out_of_band = !surely_in_range(B_high) && repaint_out_of_range_exact(Bs);
+          if (out_of_band) {
             const double inv = 1.0 / Bs;
             static_for<0, MPL>([&](auto wc) __attribute__((always_inline)) {
               const double f = inv;
