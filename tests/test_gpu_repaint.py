@@ -112,6 +112,36 @@ def test_repaint_matches_oracle(N, L, W, seed, mode, theta, waves):
         assert frac <= MAX_SHARE_NOT_IDENTICAL, f"{frac:.2e} of the floats are not bit-identical to the oracle"
 
 
+@pytest.mark.parametrize("N,L,W,seed,mode,waves,geometry", [
+    (1500, 400, 2, 46, "skew", 1, (1, 24, 2)),   # one wave, blocks of two rows
+    (2100, 400, 3, 47, "flat", 2, (2, 20, 3)),   # 33 words over two waves
+    (2100, 300, 2, 48, "skew", 1, (1, 36, 1)),   # every alpha row a checkpoint
+    (4500, 200, 2, 49, "flat", 2, (2, 36, 1)),   # ... with two waves per target
+    (1000, 600, 3, 50, "skew", 4, (4, 4, 8)),    # blocks of eight rows
+    (4000, 200, 2, 51, "flat", 8, (8, 8, 8)),    # eight waves per target
+])
+def test_repaint_geometries(N, L, W, seed, mode, waves, geometry):
+    """Wave counts, words per lane and block lengths that the benchmark's two windows do not reach, sampled targets
+    (first, last, word and wave edges) against the pinned oracle bit for bit."""
+    import torch
+    ra = _ra()
+    seq, r, wb = sy.make_chunk(N=N, L=L, W=W, seed=seed, r_mode=mode)
+    plan = ra.Plan(0, 1, waves)
+    plan.load_host(seq, r, wb)
+    plan.prepare(0.001, 0.001, 0, N)
+    g = plan.repaint_geometry()
+    plan.close()
+    assert (g["waves_per_target"], g["states_per_lane"], g["checkpoint_rows"]) == geometry
+    host_stones, res = gpu_paint_and_repaint(seq, r, 0.001, wb, range(W), waves)
+    per_wave = 64 * geometry[1]
+    targets = sorted(t for t in {0, 1, 63, 64, per_wave - 1, per_wave, N // 2, N - 2, N - 1} if t < N)
+    for w in range(W):
+        top, ls, off, pitch = res[w]
+        frac = check_window(seq, r, 0.001, host_stones, w, top, ls, off, pitch, targets)
+        _record(f"re-painting N={N} L={L} seed={seed} waves={waves} {geometry} window {w}: share of floats not bit-identical {frac:.3e}")
+        assert frac <= MAX_SHARE_NOT_IDENTICAL, f"{frac:.2e} of the floats are not bit-identical to the oracle"
+
+
 def test_repaint_known_answer_toy():
     """test/test_painting.cpp:98-133 through the GPU: with r = 0 the posterior is constant along the sequence
     and its log, in units of fast_log(theta/(1-theta)), is the asymmetric mismatch count d[k][n]."""
