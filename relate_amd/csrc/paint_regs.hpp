@@ -736,8 +736,12 @@ __device__ __forceinline__ double block_sum_hi(double (*red)[G], int& slot, uint
 // offsets behind a scalar branch: no vector instruction computes an address.  No scalar load may be in flight
 // after the wait before the barrier: the counted waits of the reads rely on LDS order.  The entries pass through
 // v[kX], v[kT] and v[kHi], which the wave sum has finished with.
+#define RELATE_XCHG_FIRST "v_add_f64 v[%[x]:%[x]+1], %[a], %[b]\n\t"
+// (the two-row backward recursion sums wa * a + wb * b, the weights in scalar registers)
+#define RELATE_XCHG_FIRST_W \
+  "v_mul_f64 v[%[x]:%[x]+1], %[b], %[kb]\n\t"  \
+  "v_fma_f64 v[%[x]:%[x]+1], %[a], %[ka], v[%[x]:%[x]+1]\n\t"
 #define RELATE_XCHG_HEAD                                                                       \
-  "v_add_f64 v[%[x]:%[x]+1], %[a], %[b]\n\t"                                                   \
   RELATE_DPP_STEP("quad_perm:[1,0,3,2]")                                                       \
   RELATE_DPP_STEP("quad_perm:[2,3,0,1]")                                                       \
   RELATE_DPP_STEP("row_half_mirror")                                                           \
@@ -804,10 +808,16 @@ __device__ __forceinline__ double block_sum_hi(double (*red)[G], int& slot, uint
   "s_waitcnt lgkmcnt(0)\n\t"                                                   \
   "v_add_f64 %[s], v[%[x]:%[x]+1], v[%[t]:%[t]+1]\n\t"
 #define RELATE_XCHG_ASM(SET, o1)                                                                                      \
-  asm volatile(RELATE_XCHG_HEAD SET(0) "s_branch .Lxsd%=\n.Lxs1%=:\n\t" SET(o1) ".Lxsd%=:"                             \
+  asm volatile(RELATE_XCHG_FIRST RELATE_XCHG_HEAD SET(0) "s_branch .Lxsd%=\n.Lxs1%=:\n\t" SET(o1) ".Lxsd%=:"           \
                : [s] "=&v"(s)                                                                                         \
                : [a] "v"(a), [b] "v"(b), [wa] "v"(wr_addr), [rb] "v"(rd_base), [step] "s"(step), [x] "n"(kX), [t] "n"(kT), \
                  [h] "n"(kHi)                                                                                         \
+               : "memory", "scc", "vcc")
+#define RELATE_XCHG_ASM_W(SET, o1)                                                                                    \
+  asm volatile(RELATE_XCHG_FIRST_W RELATE_XCHG_HEAD SET(0) "s_branch .Lxsd%=\n.Lxs1%=:\n\t" SET(o1) ".Lxsd%=:"         \
+               : [s] "=&v"(s)                                                                                         \
+               : [a] "v"(a), [b] "v"(b), [ka] "s"(wa.w), [kb] "s"(wb.w), [wa] "v"(wr_addr), [rb] "v"(rd_base),        \
+                 [step] "s"(step), [x] "n"(kX), [t] "n"(kT), [h] "n"(kHi)                                              \
                : "memory", "scc", "vcc")
 template <int G>
 __device__ __forceinline__ double exchange_sum(uint32_t wr_addr, uint32_t rd_base, int step, double a, double b)
@@ -817,6 +827,17 @@ __device__ __forceinline__ double exchange_sum(uint32_t wr_addr, uint32_t rd_bas
   if constexpr (G == 2) RELATE_XCHG_ASM(RELATE_XCHG_SET2, 16);
   else if constexpr (G == 4) RELATE_XCHG_ASM(RELATE_XCHG_SET4, 32);
   else RELATE_XCHG_ASM(RELATE_XCHG_SET8, 64);
+  return s;
+}
+// the same for wa * a + wb * b
+template <int G>
+__device__ __forceinline__ double exchange_sum(uint32_t wr_addr, uint32_t rd_base, int step, double a, ScalarWeight wa, double b, ScalarWeight wb)
+{
+  static_assert(G == 2 || G == 4 || G == 8, "waves per target");
+  double s;
+  if constexpr (G == 2) RELATE_XCHG_ASM_W(RELATE_XCHG_SET2, 16);
+  else if constexpr (G == 4) RELATE_XCHG_ASM_W(RELATE_XCHG_SET4, 32);
+  else RELATE_XCHG_ASM_W(RELATE_XCHG_SET8, 64);
   return s;
 }
 // LDS addresses for exchange_sum: `red` = the 2 x G entries; lane 62 writes set 1, every other lane's address is
@@ -1270,6 +1291,11 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     const uint64_t* rp_p = row_pointer(__builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]), stride_bytes);
     sload_words<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
     sload_words<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);
+    uint32_t wr_addr = 0, rd_base = 0;
+    if constexpr (G > 1) {
+      exchange_addresses<G>(red, wr_addr, rd_base);
+      __syncthreads();  // every wave has read the entries of the sum above
+    }
     uint64_t skn = sk_last;  // the row handled before the first step is the last SNP's; every later one is a site of the target
     for (int j = nd - 2; j >= 0; j--) {
       if ((j & 31) == 0) rotate_priority(rank, j, 1);
@@ -1288,7 +1314,12 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
       sweep_two_rows<MPL>(a0, a1, m0, m1, aa, rho, c1, skn, skc, rp_n, rp_c, rp_p);
       // B = (1-theta) * sum over matching states + theta * sum over mismatching states (:509-517)
       uint32_t B_high;
-      B = block_sum_hi<G>(red, slot, B_high, a0 + a1, w_all, m0 + m1, w_mis);
+      if constexpr (G == 1) {
+        B = block_sum_hi<G>(red, slot, B_high, a0 + a1, w_all, m0 + m1, w_mis);
+      } else {
+        B = exchange_sum<G>(wr_addr, rd_base, j, a0 + a1, w_all, m0 + m1, w_mis);
+        B_high = sgpr32((uint32_t)__double2hiint(B));
+      }
       int s_prev2;
       fetched_site<false>(s_prev2, coef_j, nx_j);
       const uint64_t* rp_p2 = row_pointer(s_prev2, stride_bytes);

@@ -53,7 +53,7 @@ def test_two_theta_kernel_on_its_golden_chunk():
 
 
 @pytest.mark.parametrize("N,G,MPL,tp,td", [(600, 2, 8, 0.001, 0.001), (600, 4, 4, 0.001, 0.001), (1100, 1, 20, 0.001, 0.001),
-                                           (600, 2, 8, 0.001, 0.01), (4000, 8, 8, 0.001, 0.001),
+                                           (600, 2, 8, 0.001, 0.01), (600, 4, 4, 0.001, 0.01), (4000, 8, 8, 0.001, 0.001),
                                            (5008, 4, 20, 0.001, 0.001), (5008, 2, 40, 0.001, 0.001)])
 def test_several_waves_and_several_rounds(N, G, MPL, tp, td):
     """Workgroups of several waves (LDS exchange through lanes 63 / 62, barrier per site), lanes of more words than a
