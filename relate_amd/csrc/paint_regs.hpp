@@ -56,8 +56,10 @@ constexpr int kPhIdx = kCS + 3;    // 2 * local word of the first padding lane (
 constexpr int kSelfM = kCS + 4;    // s[kSelfM:kSelfM+1] the target's own lane (0: another wave has it)
 constexpr int kPhM = kCS + 6;      // s[kPhM:kPhM+1] padding lanes of word kPhIdx/2
 // s[kBufA .. 91]: row words, kBufWords of them; the two-row sweeps use them as two halves of 16 registers
-constexpr int kBufA = kCS + 8, kBufC = kBufA + 16;
+constexpr int kBufA = kCS + 8;
 constexpr int kBufWords = (92 - kBufA) / 2;
+constexpr int kBufWords2 = kBufWords / 2;     // per row where a round holds the words of two rows
+constexpr int kBufC = kBufA + 2 * kBufWords2;  // the second row's words
 constexpr int kCoefN = 92, kNxN = 94;  // prefetched per-gap terms (pairs; one 4-aligned quad)
 constexpr int kDkN = 96;  // prefetched list entry
 constexpr int kCnt = 97;  // loop counter of the padding-lane writes
@@ -186,7 +188,7 @@ __device__ __forceinline__ void swait() { asm volatile("s_waitcnt lgkmcnt(0)" ::
 template <int SB, int OFF, int NW>
 __device__ __forceinline__ void sload_words(const uint64_t* p)
 {
-  static_assert(NW >= 1 && NW <= 8 && SB >= kBufA && (SB - kBufA) % 16 == 0 && SB + (NW > 4 ? 16 : 8) <= 92, "a part of the row-word registers");
+  static_assert(NW >= 1 && NW <= 8 && SB >= kBufA && SB % 4 == 0 && SB + (NW > 4 ? 16 : 8) <= 92, "a part of the row-word registers");
   if constexpr (NW > 4)
     asm volatile("s_load_dwordx16 s[%1:%1+15], %0, %2" ::"s"(p), "n"(SB), "n"(OFF) : "memory");
   else
@@ -561,11 +563,20 @@ __device__ __forceinline__ void row_acc_mis(double& m0, double& m1, uint64_t sk)
 #undef RELATE_OPS
 }
 
-// The two-row recursion takes the masks of two rows per word, so a round holds 8 words of each: those of the row
-// handled one step earlier in s[kBufA ..], those of the current row in s[kBufC ..].
+// The two-row recursion takes the masks of two rows per word, so a round holds half as many words of each (8, or 10
+// where the compiler leaves 40 registers to the row words): those of the row handled one step earlier in
+// s[kBufA ..], those of the current row in s[kBufC ..].
+// words [W0, W0 + NW) of the row at p -> s[SB ..]: eight as one load, the ninth and tenth as a load of their own
+template <int SB, int W0, int NW>
+__device__ __forceinline__ void sload_row2(const uint64_t* p)
+{
+  static_assert(NW >= 1 && NW <= kBufWords2 && NW <= 10, "one round of one row");
+  sload_words<SB, 8 * W0, (NW < 8 ? NW : 8)>(p);
+  if constexpr (NW > 8) asm volatile("s_load_dwordx4 s[%1:%1+3], %0, %2" ::"s"(p), "n"(SB + 16), "n"(8 * (W0 + 8)) : "memory");
+}
 template <int MPL>
 struct RowRounds2 {
-  static constexpr int NR = (MPL + 7) / 8;
+  static constexpr int NR = (MPL + kBufWords2 - 1) / kBufWords2;
   static constexpr int size(int r) { return MPL / NR + (r < MPL % NR ? 1 : 0); }
   static constexpr int first(int r)
   {
@@ -610,11 +621,11 @@ __device__ __forceinline__ void sweep_two_rows(double& a0, double& a1, double& m
     const uint64_t* pc = rp_c;
     const uint64_t* pq = rp_p;
     if constexpr (r + 1 < RR::NR) {
-      sload_words<kBufA, 8 * RR::first(r + 1), RR::size(r + 1)>(pn);
-      sload_words<kBufC, 8 * RR::first(r + 1), RR::size(r + 1)>(pc);
+      sload_row2<kBufA, RR::first(r + 1), RR::size(r + 1)>(pn);
+      sload_row2<kBufC, RR::first(r + 1), RR::size(r + 1)>(pc);
     } else {
-      sload_words<kBufA, 0, RR::size(0)>(pc);
-      sload_words<kBufC, 0, RR::size(0)>(pq);
+      sload_row2<kBufA, 0, RR::size(0)>(pc);
+      sload_row2<kBufC, 0, RR::size(0)>(pq);
     }
     static_for<0, NC>([&](auto cc) __attribute__((always_inline)) {
       constexpr int c = decltype(cc)::value;
@@ -1289,8 +1300,8 @@ __global__ void RELATE_REGS_ATTR __launch_bounds__(64 * G) paint_kernel_r(const 
     const uint64_t* rp_n = row_pointer(ka.p.L - 1, stride_bytes);
     const uint64_t* rp_c = row_pointer(__builtin_amdgcn_readfirstlane(dk[nd - 2]), stride_bytes);
     const uint64_t* rp_p = row_pointer(__builtin_amdgcn_readfirstlane(dk[nd > 2 ? nd - 3 : 0]), stride_bytes);
-    sload_words<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
-    sload_words<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);
+    sload_row2<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
+    sload_row2<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);
     uint32_t wr_addr = 0, rd_base = 0;
     if constexpr (G > 1) {
       exchange_addresses<G>(red, wr_addr, rd_base);

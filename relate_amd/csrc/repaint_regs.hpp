@@ -597,8 +597,8 @@ __device__ __forceinline__ void repaint_body(const RepaintKArgs& ka)
       int s_prev = seed_prev;
       const uint64_t* rp_n = rows_w + (size_t)seed_n * stride_l;
       const uint64_t* rp_c = rows_w + (size_t)s_cur * stride_l;
-      sload_words<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
-      sload_words<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);
+      sload_row2<kBufA, 0, RowRounds2<MPL>::size(0)>(rp_n);
+      sload_row2<kBufC, 0, RowRounds2<MPL>::size(0)>(rp_c);
       for (int j = jtop; j >= r0; j--) {
         {
           if ((j & 31) == 0) rotate_priority(rank, j, 0);
