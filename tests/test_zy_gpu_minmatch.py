@@ -2,8 +2,8 @@
 ABI: relate_plan_minmatch_scan on matrices in HBM -- synthetic ones with many ties, and the matrices
 relate_distance_get_matrix leaves there for SNPs of a painted chunk -- against the restated oracle: min_values bit
 for bit, the pair list entry for entry in the reference's loop order; then the host half with the reference
-generator's draws against the oracle's Initialize.  (Collected late on purpose: see the note on its first GPU run
-in DESIGN.md.)"""
+generator's draws against the oracle's Initialize.  (The file name makes pytest collect it late on purpose: a run with -x stops at
+the first failure, and one here, in the newest entry point, must not hide the tests of the hot path.)"""
 import numpy as np
 import pytest
 
